@@ -1,0 +1,136 @@
+/* mumpy_hip.h — C ABI of libmumpy_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * forward hot path of Mumpy (Multilateral Temporal-view Pyramid Transformer).
+ *
+ * The reference is pure Python/PyTorch and has no FFI of its own; the "interface" each entry point
+ * replaces is therefore the reference Python operator it computes, cited as file:line below
+ * (paths relative to the reference repo).  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions (all entry points)
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer to fp32 unless stated otherwise.
+ *   - the CALLER allocates and owns every buffer including scratch; nothing here allocates, frees or
+ *     synchronises.  Work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ *     so calls are capturable into a hipGraph.
+ *   - return 0 on success; a negative MUMPY_E* code for a rejected argument (nothing is launched);
+ *     a positive value is the hipError_t of a failed launch.  mumpy_last_error() returns a
+ *     thread-local message for the last non-zero return.  No global mutable state: reentrant.
+ *   - layouts are row-major with the last index contiguous; "token-major" means (tokens, channels).
+ *   - window size is 7 (49 tokens) and attention head width is 32 throughout (factory:26; hidden/heads).
+ */
+#ifndef MUMPY_HIP_H
+#define MUMPY_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUMPY_ABI_VERSION 1
+
+#define MUMPY_EINVAL   (-1) /* bad shape / size                              */
+#define MUMPY_EALIGN   (-2) /* pointer not 16-byte aligned where required    */
+#define MUMPY_ENULL    (-3) /* required pointer is NULL                      */
+#define MUMPY_ERANGE   (-4) /* size exceeds what the kernel was built for    */
+
+/* activation selector for mumpy_linear_fwd */
+#define MUMPY_ACT_NONE 0
+#define MUMPY_ACT_GELU 1    /* exact erf GELU, as nn.GELU() */
+
+int         mumpy_abi_version(void);
+const char* mumpy_last_error(void);
+
+/* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5, affine)  — swin:266,305; blocks:86-88 ----
+ * x, y: (rows, C) token-major; y may alias x.  C % 4 == 0, C <= 4096. */
+int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
+                        int64_t rows, int C, float eps, void* stream);
+
+/* ---- Linear: y = act(x @ W^T + bias) + residual   — nn.Linear at swin:142,164,46-49; blocks:57-71,27-33;
+ *      1x1 convs of deform:333,361,362,402; mTVE:283 (pre), mTVE:740 (globalembedding); swin:365 (reduction).
+ * x (M,K), W (N,K) [nn.Linear weight layout], bias (N) or NULL, residual (M,N) or NULL, y (M,N).
+ * fp32 in, fp32 accumulate on v_mfma_f32_32x32x2_f32.  K % 32 == 0, N % 32 == 0.  y may alias residual. */
+int mumpy_linear_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
+                     int64_t M, int N, int K, int act, void* stream);
+
+/* ---- Swin window attention core  — swin:54-83 (partition/reverse), 273,295 (roll), 145-163 (softmax(QK^T)V)
+ * qkv:  (B, Hs*W, 3*C) raster token order over the stacked grid Hs = t*H rows by W columns; channel
+ *       layout [q|k|v][head][32] exactly as nn.Linear(C,3C) emits it (swin:142).
+ * out:  (B, Hs*W, C) raster order: attention output BEFORE the output projection, already un-shifted /
+ *       window-reversed (the gather, cyclic shift, scatter are folded into the addressing; nothing is
+ *       materialised).
+ * bias: (nH,64,64) relative-position bias expanded by the caller from relative_position_bias_table
+ *       [relative_position_index] (swin:148-151), laid out [head][query i][key j], zero-padded rows
+ *       i>=49 and filled with -1e30 for key columns j>=49 (that is what masks the 49->64 padding).
+ * mask_tab: (nU,64,64) distinct attn_mask patterns padded the same way (0 / -100, swin:252), or NULL;
+ * mask_id:  (n_mask) int32 pattern index, -1 = no mask; or NULL.  Window bw (batch-major partition order) uses
+ *           mask_id[bw % n_mask] — the broadcast of swin:155 (n_mask = nW = Hs/7 * W/7 windows per image).
+ * shift: cyclic shift (0 or 3).  scale is applied to q before QK^T (swin:145). */
+int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
+                               const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
+                               float scale, void* stream);
+
+/* ---- Deformable cross-view attention (SwinDAttention, deform:324-405) — four kernels -------------- */
+
+/* offsets: q (B, H*W, C) raster, one frame per batch entry (t=1), gathered per 7x7 window.
+ * Computes, per q-window and group g<3: depthwise 5x5 conv (pad 2) -> LayerNorm(Cg) -> GELU -> 1x1 conv
+ * to 2 -> tanh * (2/7) + reference points (deform:334-349, 311-322).
+ * pos: (B*nWf, 3, 49, 2) fp32 as (y,x) in [-1,1] grid units.  dw_w (Cg,25), dw_b (Cg), ln_g/ln_b (Cg),
+ * pw_w (2,Cg).  Cg = C/3 <= 256. */
+int mumpy_deform_offsets_fwd(const float* q, const float* dw_w, const float* dw_b, const float* ln_g,
+                             const float* ln_b, const float* pw_w, float* pos, int B, int H, int W, int C,
+                             void* stream);
+
+/* sampling: x2 (B, Hs2*W, C) raster kv tokens (already through `pre`, mTVE:283), windows n2 = 0..B*nW2-1 in
+ * partition order; kv window n2 uses the offsets of q-window (n2 mod nq) (x1.repeat, deform:330).
+ * Bilinear, align_corners=True, zero padding (deform:353-356).  out: (B*nW2, 49, C) window-major. */
+int mumpy_deform_sample_fwd(const float* x2, const float* pos, float* out, int B, int Hs2, int W, int C,
+                            int nq, void* stream);
+
+/* attention + aggregation: q (B, H*W, C) raster (proj_q output); kv (B2w, 49, 2*C) window-major
+ * [k|v] (proj_k, proj_v of the sampled map); r = B2w / B1w.  For each output window b1 and head:
+ *   o[b1] = sum_{t<r} softmax(q[(b1*r+t) mod B1w] k[b1*r+t]^T * scale) v[b1*r+t]     (deform:360-395)
+ * out: (B1w, 49, C) window-major.  padmask: (1,64,64) with 0 for j<49 and -1e30 for j>=49. */
+int mumpy_deform_attention_fwd(const float* q, const float* kv, const float* padmask, float* out, int B, int H,
+                               int W, int C, int r, float scale, void* stream);
+
+/* combine (deform:403 un-permuted reshape + mTVE:138 + mTVE:285-286):
+ *   out[b, n*49+p, c] = x1[b, n*49+p, c] + x1[b, raster(n,p), c] + Yt[b*nWf+n][(p*C+c) % 49][(p*C+c) / 49]
+ * x1, out: (B, H*W, C) (out must not alias x1); Yt: (B*nWf, 49, C) = proj_out output, window-major. */
+int mumpy_deform_combine_fwd(const float* x1, const float* Yt, float* out, int B, int H, int W, int C,
+                             void* stream);
+
+/* ---- FAF: DCT band-pass features of ONE frame per clip  — dct:71-79, mTVE:734 ------------------------
+ * x: (B,T,3,224,224); D, Dt: (224,224) DCT-II matrix and its transpose (built in fp64 then cast, dct:42-45,60);
+ * out: (B,9,224,224), channel = band*3 + rgb, bands low/mid/high = i+j in [0,lo_hi], [mid_lo,mid_hi],
+ * [224,448] (dct:66-68).  scratch: B*3*224*224 floats (the spectrum). */
+int mumpy_faf_fwd(const float* x, const float* D, const float* Dt, float* scratch, float* out, int B, int T,
+                  int frame, int lo_hi, int mid_lo, int mid_hi, void* stream);
+
+/* ---- Tokenizer: Conv3d(3->C, k=s=(t,4,4)) + LayerNorm as implicit GEMM  — mTVE:605-618 ---------------
+ * x: (B,T,3,H,W); Wt: (K,C) = conv weight (C,3,t,4,4) flattened to (C,K) and transposed, K = 48*t;
+ * out: (B, t_out*(H/4)*(W/4), C) with t_out = (T - t)/t + 1, frames stacked on the token axis. */
+int mumpy_patch_embed_fwd(const float* x, const float* Wt, const float* bias, const float* gamma,
+                          const float* beta, float* out, int B, int T, int H, int W, int t, int C,
+                          float eps, void* stream);
+
+/* ---- Patch merging front half: 2x2 gather + LayerNorm(4C)  — swin:355-364 ---------------------------
+ * x: (B, Hs*W, C) on the stacked grid; out: (B, Hs/2*W/2, 4C) with channel blocks
+ * [(0,0),(1,0),(0,1),(1,1)] (row offset, col offset).  The Linear(4C->2C) is mumpy_linear_fwd. */
+int mumpy_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int B, int Hs,
+                             int W, int C, float eps, void* stream);
+
+/* ---- Temporal attention of the global ViT blocks  — blocks:57-71 under vmap(in_dims=2), mTVE:741 -----
+ * qkv: (S, T, 3*C) with S = B*49 spatial sites, heads of width 64; out: (S, T, C).  T <= 16. */
+int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T, int C, int heads,
+                                 float scale, void* stream);
+
+/* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
+int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);
+
+/* ---- out = a + b (n floats, n % 4 == 0): the residual add of CrossSwinBlock whose un-added operand is also
+ *      consumed by the next view (mTVE:275-276).  out may alias a or b. */
+int mumpy_add_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUMPY_HIP_H */

@@ -1,0 +1,147 @@
+// norm.hip — LayerNorm and the gather+LayerNorm front half of patch merging.  HBM-bound streaming kernels:
+// rows are split over LPR lanes (a power of two <= 64) with 16-byte accesses, several rows per wave when C is small,
+// the row is held in registers between the statistics pass and the normalise pass (one read, one write).
+#include "common.h"
+using namespace mumpy;
+
+namespace {
+
+constexpr int MAXNV = 16;  // float4 per lane: C <= 64 lanes * 16 * 4 = 4096
+
+// SRC: functor giving the address of float4 index v (0..C/4) of virtual row `row`.
+template <typename SRC>
+__global__ __launch_bounds__(256) void ln_rows_kernel(SRC src, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, float* __restrict__ y,
+                                                      int64_t rows, int C, int lpr, int nv, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int rpw = 64 / lpr;                      // rows per wave
+    const int sub = lane / lpr, l = lane % lpr;
+    const int64_t row = ((int64_t)blockIdx.x * 4 + wave) * rpw + sub;
+    const bool live = row < rows;
+    f32x4 v[MAXNV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXNV; ++i) {
+        if (i < nv) {
+            v[i] = live ? *reinterpret_cast<const f32x4*>(src(row, l + i * lpr)) : f32x4{0, 0, 0, 0};
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+    s = wave_sum(s, lpr);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXNV; ++i) {
+        if (i < nv) {
+            f32x4 d = v[i] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+    q = wave_sum(q, lpr);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+    float* yr = y + row * (int64_t)C;
+#pragma unroll
+    for (int i = 0; i < MAXNV; ++i) {
+        if (i < nv) {
+            const int c4 = l + i * lpr;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+            *reinterpret_cast<f32x4*>(yr + 4 * c4) = (v[i] - mean) * rstd * g + b;
+        }
+    }
+}
+
+struct PlainRows {
+    const float* x;
+    int C;
+    __device__ const float* operator()(int64_t row, int c4) const { return x + row * (int64_t)C + 4 * c4; }
+};
+
+// virtual row of patch merging: out token (b, i, j) = concat of x tokens (2i,2j),(2i+1,2j),(2i,2j+1),(2i+1,2j+1)
+// (swin:357-361) on the stacked (Hs,W) grid.
+struct MergeRows {
+    const float* x;
+    int Hs, W, C;  // C = per-token channels of x (virtual row has 4C)
+    __device__ const float* operator()(int64_t row, int c4) const {
+        const int w2 = W >> 1, h2 = Hs >> 1;
+        const int j = (int)(row % w2);
+        const int64_t t = row / w2;
+        const int i = (int)(t % h2);
+        const int64_t b = t / h2;
+        const int seg = (4 * c4) / C;            // which of the 4 source tokens
+        const int c = 4 * c4 - seg * C;
+        const int dy = seg & 1, dx = seg >> 1;   // order (0,0),(1,0),(0,1),(1,1)
+        const int64_t tok = (b * Hs + (2 * i + dy)) * (int64_t)W + (2 * j + dx);
+        return x + tok * C + c;
+    }
+};
+
+bool pick_split(int C, int* lpr, int* nv) {
+    if (C % 4 || C > 4096 || C < 4) return false;
+    const int n4 = C / 4;
+    int l = 64;
+    while (l > 1 && (n4 % l)) l >>= 1;
+    while (n4 / l > MAXNV) return false;
+    *lpr = l;
+    *nv = n4 / l;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
+                                   int C, float eps, void* stream) {
+    MUMPY_REQUIRE(x && gamma && beta && y, MUMPY_ENULL, "layernorm: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), MUMPY_EALIGN,
+                  "layernorm: pointers must be 16-byte aligned");
+    int lpr, nv;
+    MUMPY_REQUIRE(rows >= 0 && pick_split(C, &lpr, &nv), MUMPY_EINVAL, "layernorm: unsupported C=%d", C);
+    if (rows == 0) return 0;
+    const int rows_per_block = 4 * (64 / lpr);
+    const int64_t grid = (rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(ln_rows_kernel<PlainRows>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                       PlainRows{x, C}, gamma, beta, y, rows, C, lpr, nv, eps);
+    MUMPY_CHECK_LAUNCH("layernorm");
+    return 0;
+}
+
+extern "C" int mumpy_patch_merge_ln_fwd(const float* x, const float* gamma, const float* beta, float* out, int B,
+                                        int Hs, int W, int C, float eps, void* stream) {
+    MUMPY_REQUIRE(x && gamma && beta && out, MUMPY_ENULL, "patch_merge_ln: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), MUMPY_EALIGN,
+                  "patch_merge_ln: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && Hs > 0 && W > 0 && (Hs % 2 == 0) && (W % 2 == 0), MUMPY_EINVAL,
+                  "patch_merge_ln: grid (%d,%d) must be even (swin:353)", Hs, W);
+    int lpr, nv;
+    MUMPY_REQUIRE(C % 4 == 0 && pick_split(4 * C, &lpr, &nv), MUMPY_EINVAL, "patch_merge_ln: unsupported C=%d", C);
+    const int64_t rows = (int64_t)B * (Hs / 2) * (W / 2);
+    const int rows_per_block = 4 * (64 / lpr);
+    const int64_t grid = (rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL(ln_rows_kernel<MergeRows>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                       MergeRows{x, Hs, W, C}, gamma, beta, out, rows, 4 * C, lpr, nv, eps);
+    MUMPY_CHECK_LAUNCH("patch_merge_ln");
+    return 0;
+}
+
+// ------------------------------------------------------------------ eval tail: sigmoid -> threshold -> uint8
+namespace {
+__global__ __launch_bounds__(256) void sigmoid_thr_kernel(const float* __restrict__ z, uint8_t* __restrict__ m,
+                                                          int64_t n, float thr) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) m[i] = (1.0f / (1.0f + __expf(-z[i])) > thr) ? 1 : 0;
+}
+}  // namespace
+
+extern "C" int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream) {
+    MUMPY_REQUIRE(logits && mask, MUMPY_ENULL, "sigmoid_threshold: null pointer");
+    MUMPY_REQUIRE(n >= 0, MUMPY_EINVAL, "sigmoid_threshold: n < 0");
+    if (n == 0) return 0;
+    int64_t grid = (n + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(sigmoid_thr_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), logits, mask, n, thr);
+    MUMPY_CHECK_LAUNCH("sigmoid_threshold");
+    return 0;
+}

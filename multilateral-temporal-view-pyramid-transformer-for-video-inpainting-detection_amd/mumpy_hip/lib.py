@@ -1,0 +1,67 @@
+"""Loader for libmumpy_hip.so.  Fails loudly: there is no fallback implementation."""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PKG = os.path.dirname(_HERE)
+_LIB = None
+
+c_f = ctypes.c_void_p      # device pointers travel as void*
+c_i = ctypes.c_int
+c_l = ctypes.c_int64
+c_fl = ctypes.c_float
+
+# name -> argtypes; mirrors include/mumpy_hip.h one to one (tests/test_abi.py checks the header against this)
+SIGNATURES = {
+    "mumpy_layernorm_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_fl, c_f],
+    "mumpy_linear_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f],
+    "mumpy_window_attention_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_deform_offsets_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_deform_sample_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_deform_attention_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_deform_combine_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_faf_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_patch_embed_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_patch_merge_ln_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_temporal_attention_fwd": [c_f, c_f, c_l, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_sigmoid_threshold_fwd": [c_f, c_f, c_l, c_fl, c_f],
+    "mumpy_add_fwd": [c_f, c_f, c_f, c_l, c_f],
+}
+ABI_VERSION = 1
+
+
+def library_path() -> str:
+    return os.environ.get("MUMPY_HIP_LIB", os.path.join(_PKG, "lib", "libmumpy_hip.so"))
+
+
+def build_library(verbose: bool = False) -> str:
+    """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-j8"], capture_output=True, text=True)
+    if verbose or r.returncode:
+        print(r.stdout[-4000:], r.stderr[-4000:])
+    if r.returncode:
+        raise RuntimeError("building libmumpy_hip.so failed (see output above)")
+    return library_path()
+
+
+def load_library():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"libmumpy_hip.so not found at {path}: the HIP kernels are the only implementation of this package "
+            "(no CPU/torch fallback). Build it with `python __graft_entry__.py` or `make -C <pkg>/csrc`.")
+    lib = ctypes.CDLL(path)
+    lib.mumpy_abi_version.restype = c_i
+    lib.mumpy_last_error.restype = ctypes.c_char_p
+    if lib.mumpy_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.mumpy_abi_version()} != binding {ABI_VERSION}; rebuild")
+    for name, args in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = the library is stale: fail loudly
+        fn.argtypes = args
+        fn.restype = c_i
+    _LIB = lib
+    return lib

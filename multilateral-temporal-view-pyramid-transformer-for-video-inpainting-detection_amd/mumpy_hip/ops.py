@@ -1,0 +1,211 @@
+"""Tensor-level wrappers over the C ABI.  Each takes/returns torch CUDA(HIP) fp32 tensors, allocates outputs with
+torch (caching allocator => graph-capturable), and enqueues on torch's current stream.  No fallbacks."""
+import math
+from typing import Optional
+
+import torch
+
+from .lib import load_library
+
+ACT_NONE, ACT_GELU = 0, 1
+NEG = -1e30
+
+
+def _lib():
+    return load_library()
+
+
+def _chk(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError(f"mumpy_hip: {name} is on {t.device}; the HIP kernels need a GPU tensor (there is no CPU path)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"mumpy_hip: {name} must be float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+# Optional per-launch timing (bench.py): when PROFILE is a dict, every C-ABI call is bracketed by events on the
+# stream it is launched on and recorded as PROFILE[name] -> [(start_event, end_event, work), ...].
+PROFILE = None
+
+
+def _call(name, *args, work=0.0):
+    lib = _lib()
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(lib, name)(*args)
+        e1.record()
+        PROFILE.setdefault(name, []).append((e0, e1, work))
+    else:
+        rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (rc={rc}): {lib.mumpy_last_error().decode()}")
+
+
+# ------------------------------------------------------------------------------------------------
+def layernorm(x, gamma, beta, eps=1e-5, out=None):
+    x = _chk(x, "x")
+    c = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    _call("mumpy_layernorm_fwd", _p(x), _p(_chk(gamma, "gamma")), _p(_chk(beta, "beta")), _p(out), x.numel() // c, c,
+          eps, _stream(), work=8.0 * x.numel())
+    return out
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
+    """y = act(x @ weight.T + bias) + residual; weight (N,K) or a 1x1-conv kernel (N,K,1,1)."""
+    x = _chk(x, "x")
+    weight = _chk(weight, "weight")
+    n, k = weight.shape[0], weight.numel() // weight.shape[0]
+    if x.shape[-1] != k:
+        raise RuntimeError(f"linear: x has {x.shape[-1]} features, weight expects {k}")
+    m = x.numel() // k
+    if out is None:
+        out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+        if residual.numel() != m * n:
+            raise RuntimeError("linear: residual shape mismatch")
+    _call("mumpy_linear_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out),
+          m, n, k, act, _stream(), work=2.0 * m * n * k)
+    return out
+
+
+def add(a, b, out=None):
+    a, b = _chk(a, "a"), _chk(b, "b")
+    out = torch.empty_like(a) if out is None else out
+    _call("mumpy_add_fwd", _p(a), _p(b), _p(out), a.numel(), _stream())
+    return out
+
+
+def expand_relpos_bias(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """relative_position_bias_table (169,nH) + relative_position_index (49,49) -> (nH,64,64) padded bias
+    [head][query][key]: rows >= 49 zero, key columns >= 49 = -1e30 (swin:148-151)."""
+    nh = table.shape[1]
+    b = table[index.reshape(-1)].reshape(49, 49, nh).permute(2, 0, 1)
+    out = torch.zeros(nh, 64, 64, device=table.device, dtype=torch.float32)
+    out[:, :, 49:] = NEG
+    out[:, :49, :49] = b
+    return out
+
+
+def pad_mask() -> torch.Tensor:
+    m = torch.zeros(1, 64, 64, dtype=torch.float32)
+    m[:, :, 49:] = NEG
+    return m
+
+
+def compact_attn_mask(mask: torch.Tensor):
+    """attn_mask (nW,49,49) of 0/-100 (swin:252) -> (mask_tab (nU,64,64), mask_id (nW) int32, -1 = all-zero)."""
+    m = mask.detach().float().cpu().reshape(mask.shape[0], -1)
+    uniq, inv = torch.unique(m, dim=0, return_inverse=True)
+    nz = [i for i in range(uniq.shape[0]) if bool((uniq[i] != 0).any())]
+    remap = torch.full((uniq.shape[0],), -1, dtype=torch.int32)
+    for j, i in enumerate(nz):
+        remap[i] = j
+    tab = torch.zeros(max(len(nz), 1), 64, 64)
+    for j, i in enumerate(nz):
+        tab[j, :49, :49] = uniq[i].reshape(49, 49)
+    return tab.to(mask.device), remap[inv].to(torch.int32).to(mask.device)
+
+
+def window_attention(qkv, bias_pad, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None, out=None):
+    """qkv (B, hs*w, 3C) raster -> (B, hs*w, C) raster attention output (before proj)."""
+    qkv = _chk(qkv, "qkv")
+    if qkv.numel() != b * hs * w * 3 * c:
+        raise RuntimeError("window_attention: qkv shape mismatch")
+    out = torch.empty(b, hs * w, c, device=qkv.device, dtype=torch.float32) if out is None else out
+    n_mask = 0 if mask_id is None else mask_id.numel()
+    _call("mumpy_window_attention_fwd", _p(qkv), _p(out), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
+          b, hs, w, c, shift, scale, _stream(), work=307328.0 * b * (hs // 7) * (w // 7) * (c // 32))
+    return out
+
+
+def deform_offsets(q, dw_w, dw_b, ln_g, ln_b, pw_w, b, h, w, c):
+    q = _chk(q, "q")
+    nwin = b * (h // 7) * (w // 7)
+    pos = torch.empty(nwin, 3, 49, 2, device=q.device, dtype=torch.float32)
+    _call("mumpy_deform_offsets_fwd", _p(q), _p(_chk(dw_w, "dw_w")), _p(_chk(dw_b, "dw_b")), _p(_chk(ln_g, "ln_g")),
+          _p(_chk(ln_b, "ln_b")), _p(_chk(pw_w, "pw_w")), _p(pos), b, h, w, c, _stream())
+    return pos
+
+
+def deform_sample(x2, pos, b, hs2, w, c, nq):
+    x2 = _chk(x2, "x2")
+    nw2 = b * (hs2 // 7) * (w // 7)
+    out = torch.empty(nw2, 49, c, device=x2.device, dtype=torch.float32)
+    _call("mumpy_deform_sample_fwd", _p(x2), _p(_chk(pos, "pos")), _p(out), b, hs2, w, c, nq, _stream(),
+          work=4.0 * (2 * nw2 * 49 * c + nw2 * 3 * 49 * 2))       # bytes: read kv once, write sampled once, read offsets
+    return out
+
+
+def deform_attention(q, kv, padmask, b, h, w, c, r, scale):
+    q, kv = _chk(q, "q"), _chk(kv, "kv")
+    b1w = b * (h // 7) * (w // 7)
+    if kv.numel() != b1w * r * 49 * 2 * c:
+        raise RuntimeError("deform_attention: kv shape mismatch")
+    out = torch.empty(b1w, 49, c, device=q.device, dtype=torch.float32)
+    _call("mumpy_deform_attention_fwd", _p(q), _p(kv), _p(_chk(padmask, "padmask")), _p(out), b, h, w, c, r, scale,
+          _stream(), work=307328.0 * b1w * r * (c // 32))
+    return out
+
+
+def deform_combine(x1, yt, b, h, w, c):
+    x1, yt = _chk(x1, "x1"), _chk(yt, "yt")
+    out = torch.empty_like(x1)
+    _call("mumpy_deform_combine_fwd", _p(x1), _p(yt), _p(out), b, h, w, c, _stream())
+    return out
+
+
+def faf(x, d, dt, frame, lo_hi, mid_lo, mid_hi):
+    x = _chk(x, "x")
+    b, t = x.shape[0], x.shape[1]
+    if tuple(x.shape[2:]) != (3, 224, 224):
+        raise RuntimeError(f"faf: expects (B,T,3,224,224) clips (dct.py:57,72), got {tuple(x.shape)}")
+    scratch = torch.empty(b, 3, 224, 224, device=x.device, dtype=torch.float32)
+    out = torch.empty(b, 9, 224, 224, device=x.device, dtype=torch.float32)
+    _call("mumpy_faf_fwd", _p(x), _p(_chk(d, "D")), _p(_chk(dt, "Dt")), _p(scratch), _p(out), b, t, frame, lo_hi, mid_lo,
+          mid_hi, _stream())
+    return out
+
+
+def patch_embed(x, wt, bias, gamma, beta, t, eps=1e-5):
+    """x (B,T,3,H,W), wt (48t, C) -> (B, t_out*H/4*W/4, C)."""
+    x = _chk(x, "x")
+    b, tt, _, h, w = x.shape
+    c = wt.shape[1]
+    t_out = (tt - t) // t + 1
+    out = torch.empty(b, t_out * (h // 4) * (w // 4), c, device=x.device, dtype=torch.float32)
+    _call("mumpy_patch_embed_fwd", _p(x), _p(_chk(wt, "wt")), _p(_chk(bias, "bias")), _p(_chk(gamma, "gamma")),
+          _p(_chk(beta, "beta")), _p(out), b, tt, h, w, t, c, eps, _stream())
+    return out
+
+
+def patch_merge_ln(x, gamma, beta, b, hs, w, c, eps=1e-5):
+    x = _chk(x, "x")
+    out = torch.empty(b, (hs // 2) * (w // 2), 4 * c, device=x.device, dtype=torch.float32)
+    _call("mumpy_patch_merge_ln_fwd", _p(x), _p(_chk(gamma, "gamma")), _p(_chk(beta, "beta")), _p(out), b, hs, w, c, eps,
+          _stream())
+    return out
+
+
+def temporal_attention(qkv, s, t, c, heads, scale):
+    qkv = _chk(qkv, "qkv")
+    out = torch.empty(s, t, c, device=qkv.device, dtype=torch.float32)
+    _call("mumpy_temporal_attention_fwd", _p(qkv), _p(out), s, t, c, heads, scale, _stream())
+    return out
+
+
+def sigmoid_threshold(logits, thr=0.5):
+    logits = _chk(logits, "logits")
+    mask = torch.empty(logits.shape, device=logits.device, dtype=torch.uint8)
+    _call("mumpy_sigmoid_threshold_fwd", _p(logits), _p(mask), logits.numel(), thr, _stream())
+    return mask

@@ -1,0 +1,337 @@
+"""GPU (-m gpu): the HIP path, called through the C ABI, against (a) the oracle on the same seeded inputs and
+(b) the committed goldens that the real reference produced.  Bar (BASELINE.json north_star): <= 1e-3 relative in
+fp32 (max-abs error over max-abs reference), bit-exact for window-partition indexing."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, check_digest, golden_input, rel_err
+from weight_fill import fill_module_, fill_state_dict_, seeded_randn
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # the north_star bar
+TIGHT = 5e-5        # what single operators are expected to meet in practice (fp32 MFMA = exact fma chain)
+
+if torch.cuda.is_available():
+    from oracle import mumpy_oracle as O
+    from mumpy_hip import ops
+    DEV = torch.device("cuda:0")
+
+
+def cpu_sd(m, prefix=""):
+    return {prefix + k: v.detach().cpu() for k, v in m.state_dict().items()}
+
+
+# ------------------------------------------------------------------ elementwise / norm / GEMM
+@pytest.mark.parametrize("c", [32, 96, 128, 192, 256, 384, 512, 768, 1024, 1536, 2048, 3072, 4096])
+def test_layernorm(c):
+    x = seeded_randn(c, 37, c) * 3 + 1
+    g, b = seeded_randn(c + 1, c), seeded_randn(c + 2, c)
+    y = ops.layernorm(x.to(DEV), g.to(DEV), b.to(DEV))
+    ref = F.layer_norm(x.double(), (c,), g.double(), b.double(), 1e-5)
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
+def test_layernorm_empty_and_inplace():
+    g, b = torch.ones(96, device=DEV), torch.zeros(96, device=DEV)
+    assert ops.layernorm(torch.zeros(0, 96, device=DEV), g, b).shape == (0, 96)
+    x = seeded_randn(5, 130, 96).to(DEV)
+    ref = ops.layernorm(x, g, b)
+    ops.layernorm(x, g, b, out=x)
+    assert torch.equal(x, ref)
+
+
+@pytest.mark.parametrize("m,n,k", [(392, 96, 96), (1, 128, 32), (129, 288, 96), (1568, 384, 1536), (300, 768, 2560),
+                                   (257, 2304, 768), (1000, 512, 128), (64, 96, 384), (131, 192, 384), (50, 3072, 768)])
+@pytest.mark.parametrize("act,res", [(0, False), (1, True)])
+def test_linear(m, n, k, act, res):
+    x, w, b = seeded_randn(m, m, k), seeded_randn(n, n, k) / k ** 0.5, seeded_randn(k, n)
+    r = seeded_randn(m + n, m, n) if res else None
+    y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=act, residual=None if r is None else r.to(DEV))
+    ref = F.linear(x.double(), w.double(), b.double())
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
+def test_linear_no_bias_and_alias():
+    x, w = seeded_randn(1, 200, 128).to(DEV), seeded_randn(2, 128, 128).to(DEV) / 11
+    r = seeded_randn(3, 200, 128).to(DEV)
+    ref = ops.linear(x, w, None, residual=r)
+    out = r.clone()
+    ops.linear(x, w, None, residual=out, out=out)               # y may alias residual
+    assert torch.equal(out, ref)
+    assert rel_err(ref.cpu(), x.cpu().double() @ w.cpu().double().t() + r.cpu().double()) < 1e-5
+
+
+def test_add():
+    a, b = seeded_randn(1, 7, 196, 96).to(DEV), seeded_randn(2, 7, 196, 96).to(DEV)
+    assert torch.equal(ops.add(a, b), a + b)
+
+
+# ------------------------------------------------------------------ bit-exact window indexing through the kernel
+@pytest.mark.parametrize("hs,w,shift", [(56, 56, 0), (56, 56, 3), (168, 56, 3), (280, 56, 3), (42, 14, 3), (7, 7, 0)])
+def test_window_indexing_bit_exact(index_golden, hs, w, shift):
+    """A one-hot 'attention' (bias 0 on (i, (i+1)%49), -1e30 elsewhere) makes the kernel copy V rows exactly:
+    out[token at window slot i] == V[token at window slot i+1], which pins gather, roll and scatter bit for bit."""
+    c, nh, b = 64, 2, 2
+    l = hs * w
+    qkv = torch.zeros(b, l, 3 * c)
+    v = torch.arange(b * l * c, dtype=torch.float32).reshape(b, l, c) % 4093     # exactly representable
+    qkv[:, :, 2 * c:] = v
+    bias = torch.full((nh, 64, 64), -1e30)
+    for i in range(49):
+        bias[:, i, (i + 1) % 49] = 0.0
+    bias[:, 49:, :] = 0.0
+    bias[:, :, 49:] = -1e30
+    out = ops.window_attention(qkv.to(DEV), bias.to(DEV), b, hs, w, c, shift, 32 ** -0.5).cpu()
+    key = (f"rollpart_{hs}x{w}" if shift else f"part_{hs}x{w}")
+    idx = torch.tensor(index_golden[key].astype(np.int64)) if key in index_golden.files else O.window_token_index(hs, w, shift)
+    assert torch.equal(idx, O.window_token_index(hs, w, shift))
+    idxw = idx.view(-1, 49)
+    expect = torch.empty_like(v)
+    expect[:, idxw.reshape(-1)] = v[:, torch.roll(idxw, -1, dims=1).reshape(-1)]
+    assert torch.equal(out, expect)
+
+
+# ------------------------------------------------------------------ per-operator parity vs reference goldens + oracle
+def test_window_attention_module(ops_golden):
+    from models.modules.swinTransformer import WindowAttention
+    wa = fill_module_(WindowAttention(96, (7, 7), 3).eval(), "wa/").to(DEV)
+    x = golden_input(ops_golden, "wa/x").to(DEV)
+    assert rel_err(wa(x).cpu(), ops_golden["wa/y_nomask"]) < TIGHT
+    mask = torch.tensor(ops_golden["wa/mask"]).to(DEV)
+    assert rel_err(wa(x, mask=mask).cpu(), ops_golden["wa/y_mask"]) < TIGHT
+
+
+@pytest.mark.parametrize("tag,shift,t", [("stb_s3_t3", 3, 3), ("stb_s0_t1", 0, 1)])
+def test_swin_block(ops_golden, tag, shift, t):
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = fill_module_(SwinTransformerBlock(96, (14, 14), 3, shift_size=shift, temporal_dim=t).eval(), tag + "/").to(DEV)
+    x = golden_input(ops_golden, tag + "/x")
+    y = blk(x.to(DEV)).cpu()
+    assert rel_err(y, ops_golden[tag + "/y"]) < TIGHT
+    assert rel_err(y, O.swin_block(x, cpu_sd(blk, "b."), "b", 14 * t, 14, shift)) < TIGHT
+
+
+@pytest.mark.parametrize("r", [1, 3, 5])
+def test_swin_dattention(ops_golden, r):
+    from models.modules.deformableAttention import SwinDAttention
+    tag = f"sda_r{r}"
+    m = fill_module_(SwinDAttention(96, 3, 0.0, n_groups=3).eval(), tag + "/").to(DEV)
+    x1, x2 = golden_input(ops_golden, tag + "/x1"), golden_input(ops_golden, tag + "/x2")
+    y, attn = m(x1.to(DEV), x2.to(DEV))
+    assert attn is None
+    assert rel_err(y.cpu(), ops_golden[tag + "/y"]) < TIGHT
+    assert rel_err(y.cpu(), O.swin_dattention(x1, x2, cpu_sd(m, "d."), "d")) < TIGHT
+
+
+@pytest.mark.parametrize("c,nh", [(192, 6), (384, 12), (768, 24)])
+def test_swin_dattention_wide(c, nh):
+    """Group widths 64/128/256 (stages 1-3) against the oracle; no reference golden at these widths."""
+    from models.modules.deformableAttention import SwinDAttention
+    m = fill_module_(SwinDAttention(c, nh, 0.0, n_groups=3).eval(), f"sdaw{c}/").to(DEV)
+    x1, x2 = seeded_randn(c, 2, 49, c), seeded_randn(c + 1, 6, 49, c)
+    y, _ = m(x1.to(DEV), x2.to(DEV))
+    assert rel_err(y.cpu(), O.swin_dattention(x1, x2, cpu_sd(m, "d."), "d")) < TIGHT
+
+
+def test_deform_sampling_hits_zero_padding():
+    """Force sample points outside the window (zeros padding branch of grid_sample, deform:353-356)."""
+    c = 96
+    x2 = seeded_randn(5, 3, 49, c)
+    pos = (torch.rand(3, 3, 49, 2, generator=torch.Generator().manual_seed(9)) * 2.8 - 1.4)
+    out = ops.deform_sample(x2.to(DEV), pos.to(DEV), 3, 7, 7, c, 3).cpu()
+    ref = O.bilinear_sample_window(x2, pos)
+    assert float((pos.abs() > 1).float().mean()) > 0.2
+    assert rel_err(out, ref) < 1e-5
+
+
+def test_cross_swin_block(ops_golden):
+    from models.encoder.multiTemporalViewEncoder import CrossSwinBlock
+    m = fill_module_(CrossSwinBlock(96, 128, (14, 14), 3, temporal_dims=1).eval(), "csb/").to(DEV)
+    x1, x2 = golden_input(ops_golden, "csb/x1"), golden_input(ops_golden, "csb/x2")
+    y, out = m(x1.to(DEV), x2.to(DEV))
+    assert rel_err(out.cpu(), ops_golden["csb/out"]) < TIGHT
+    assert rel_err(y.cpu(), ops_golden["csb/y"]) < TIGHT
+    m = fill_module_(CrossSwinBlock(128, 128, (14, 14), 4, last_view=True, temporal_dims=3).eval(), "csbl/").to(DEV)
+    x1 = golden_input(ops_golden, "csbl/x1")
+    y, out = m(x1.to(DEV), x1.to(DEV))
+    assert rel_err(out.cpu(), ops_golden["csbl/out"]) < TIGHT
+    assert rel_err(y.cpu(), ops_golden["csbl/y"]) < TIGHT
+
+
+def test_patch_merging(ops_golden):
+    from models.modules.swinTransformer import PatchMerging
+    m = fill_module_(PatchMerging((42, 14), 96).eval(), "pm/").to(DEV)
+    y = m(golden_input(ops_golden, "pm/x").to(DEV)).cpu()
+    assert rel_err(y, ops_golden["pm/y"]) < TIGHT
+
+
+def test_faf(ops_golden):
+    from models.modules.dct import FAF
+    x = golden_input(ops_golden, "faf/x")
+    faf = FAF()
+    y = faf.forward_frame(x.to(DEV), 1).cpu()
+    assert rel_err(y[:, :, ::4, ::4], ops_golden["faf/y_sub4"]) < TIGHT
+    assert rel_err(y[:, :, 100:104], ops_golden["faf/y_rows"]) < TIGHT
+    check_digest(y, ops_golden, "faf/y", TIGHT)
+    assert rel_err(y, O.faf_frame1(x)) < TIGHT
+    # property: the three bands of a frame are an orthogonal split; low+mid overlap only on i+j == 79
+    full = faf(x[:, :2].to(DEV))
+    assert full.shape == (1, 2, 9, 224, 224) and torch.equal(full[:, 1].cpu(), y)
+
+
+def test_global_block(ops_golden):
+    from models.modules.blocks import Block
+    m = fill_module_(Block(768, 12, 3072, 0.0, 0.0).eval(), "gb/").to(DEV)
+    y = m(golden_input(ops_golden, "gb/x").to(DEV)).cpu()
+    assert rel_err(y, ops_golden["gb/y"]) < TIGHT
+
+
+@pytest.mark.parametrize("t", [1, 2, 5, 9, 16])
+def test_temporal_attention_lengths(t):
+    s, c, heads = 7, 768, 12
+    qkv = seeded_randn(t, s, t, 3 * c)
+    out = ops.temporal_attention(qkv.to(DEV), s, t, c, heads, 64 ** -0.5).cpu()
+    q, k, v = qkv.double().reshape(s, t, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1)) * 64 ** -0.5).softmax(-1) @ v
+    assert rel_err(out, ref.transpose(1, 2).reshape(s, t, c)) < 1e-5
+
+
+def test_tokenizer(ops_golden):
+    from models.encoder.multiTemporalViewEncoder import CrossThreeViewTokenize
+    from models.factory.modelFactory import multiswin_view_configs
+    tk = fill_module_(CrossThreeViewTokenize(multiswin_view_configs(3)).eval(), "tok/").to(DEV)
+    ys = tk(golden_input(ops_golden, "tok/x").to(DEV))
+    for i, y in enumerate(ys):
+        y = y.cpu()
+        shp = ops_golden[f"tok/shape{i}"]
+        assert y.shape == (shp[0], shp[1] * shp[2], shp[3])
+        assert rel_err(y.reshape(-1, y.shape[-1])[:64], ops_golden[f"tok/y{i}_head"]) < TIGHT
+        check_digest(y, ops_golden, f"tok/y{i}", TIGHT)
+
+
+def test_tokenizer_long_tubelet_t9():
+    """T = 9 (config 4's temporal length): K = 432 needs > 64 KB of LDS; checked against the oracle."""
+    from models.encoder.multiTemporalViewEncoder import CrossThreeViewTokenize
+    from models.factory.modelFactory import multiswin_view_configs
+    tk = fill_module_(CrossThreeViewTokenize(multiswin_view_configs(9)).eval(), "tok9/").to(DEV)
+    x = seeded_randn(99, 1, 9, 3, 224, 224)
+    ys = tk(x.to(DEV))
+    ref = O.tokenize(x, cpu_sd(tk, "t."), O.MumpyConfig(frames=9), "t")
+    for y, r in zip(ys, ref):
+        assert rel_err(y.cpu(), r) < TIGHT
+
+
+def test_sigmoid_threshold():
+    z = seeded_randn(4, 2, 1, 224, 224)
+    z[0, 0, 0, :4] = torch.tensor([0.0, 1e-7, -1e-7, 30.0])
+    m = ops.sigmoid_threshold(z.to(DEV)).cpu()
+    assert torch.equal(m, O.mask_from_logits(z))
+
+
+# ------------------------------------------------------------------ whole model vs the reference goldens
+def _load_filled(module, device):
+    fill_module_(module)
+    return module.to(device).eval()
+
+
+def _check_full(store, tag, logits, feats, fx, vx, dx, tol):
+    assert rel_err(logits, store[tag + "/logits"]) < tol
+    assert rel_err(fx, store[tag + "/final_x"]) < tol
+    check_digest(dx, store, tag + "/dct_x", tol)
+    check_digest(feats, store, tag + "/x_feats", tol)
+    for s in range(4):
+        for v in range(3):
+            assert list(vx[s][v].shape) == list(store[f"{tag}/view_shape_{s}_{v}"])
+            check_digest(vx[s][v].cpu(), store, f"{tag}/view_{s}_{v}", tol)
+
+
+@pytest.fixture(scope="module")
+def model_t3():
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    return _load_filled(Encoder(), DEV), _load_filled(Decoder(), DEV)
+
+
+@pytest.mark.parametrize("tag", ["b1t3", "b2t3"])
+def test_full_model_t3(full_golden, model_t3, tag):
+    enc, dec = model_t3
+    x = golden_input(full_golden, tag + "/x").to(DEV)
+    with torch.no_grad():
+        fx, vx, dx = enc(x)
+        logits, feats = dec(fx, vx, dx)
+    _check_full(full_golden, tag, logits.cpu(), feats.cpu(), fx.cpu(), vx, dx.cpu(), TOL)
+    # the product of the path: the binary mask (test.py:100-108) must agree except within round-off of the threshold
+    ref_logits = torch.tensor(full_golden[tag + "/logits"])
+    flips = (ops.sigmoid_threshold(logits).cpu() != O.mask_from_logits(ref_logits))
+    assert float(flips.float().mean()) < 1e-4
+    assert bool((ref_logits[flips].abs() < 1e-3).all())
+
+
+def test_full_model_matches_oracle_and_couples_batch(full_golden, model_t3):
+    enc, dec = model_t3
+    x = golden_input(full_golden, "b2t3/x")
+    with torch.no_grad():
+        l2 = dec(*enc(x.to(DEV)))[0].cpu()
+        l1 = dec(*enc(x[:1].to(DEV)))[0].cpu()
+        lo = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)[0]
+    assert rel_err(l2, lo) < TOL
+    assert rel_err(l2[:1], l1) > 1e-3           # samples of a micro-batch are coupled
+
+
+def test_full_model_t5(full_golden):
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = golden_input(full_golden, "b1t5/x").to(DEV)
+    with torch.no_grad():
+        fx, vx, dx = enc(x)
+        logits, feats = dec(fx, vx, dx)
+    _check_full(full_golden, "b1t5", logits.cpu(), feats.cpu(), fx.cpu(), vx, dx.cpu(), TOL)
+
+
+def test_baseline_encoder(full_golden):
+    from models.encoder.encoder import BaselineEncoder
+    enc = _load_filled(BaselineEncoder(), DEV)
+    with torch.no_grad():
+        y = enc(golden_input(full_golden, "base_b1t3/x").to(DEV))
+    assert rel_err(y.cpu(), full_golden["base_b1t3/y"]) < TOL
+
+
+def test_strict_checkpoint_roundtrip(tmp_path, model_t3):
+    """a reference-format checkpoint (encoder_{e}.pt = plain state_dict) loads strictly and reproduces
+    the outputs; 'module.'-prefixed (DataParallel) checkpoints are what utils/utils.py:156-176 strips."""
+    from models.encoder.encoder import Encoder
+    enc, _ = model_t3
+    path = tmp_path / "encoder_0.pt"
+    torch.save(enc.state_dict(), path)
+    e2 = Encoder()
+    e2.load_state_dict(torch.load(path, map_location="cpu", weights_only=True), strict=True)
+    e2 = e2.to(DEV).eval()
+    x = seeded_randn(77, 1, 3, 3, 224, 224).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(enc(x)[0], e2(x)[0])
+
+
+def test_hip_graph_replay_is_identical(model_t3):
+    """The whole forward is capturable into one hipGraph (no allocation, sync or host round trip inside)."""
+    from mumpy_hip.graph import GraphedForward
+    enc, dec = model_t3
+    x = seeded_randn(78, 1, 3, 3, 224, 224).to(DEV)
+    with torch.no_grad():
+        eager = dec(*enc(x))[0].clone()
+    g = GraphedForward(enc, dec, x)
+    assert torch.equal(g(x)[0], eager)
+    x2 = seeded_randn(79, 1, 3, 3, 224, 224).to(DEV)
+    with torch.no_grad():
+        eager2 = dec(*enc(x2))[0]
+    assert torch.equal(g(x2)[0], eager2)
