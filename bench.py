@@ -1,0 +1,252 @@
+#!/usr/bin/env python3
+"""bench.py — forward clips/s of the Mumpy hot path (encoder + decoder) on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[1]): per rank a micro-batch of B=8 synthetic clips, T=5, 224x224, fp32, full Mumpy
+(three temporal views with tubelets (5,4,1), pyramid decoder), synthetic deterministic weights.  A "step" is one forward
+of one micro-batch per rank (weak scaling: clips are independent across micro-batches, so ranks shard the batch axis with
+no data-path collective; the only collective is ONE all-reduce of the 3-float metric vector after the timed loop's last
+step — SURVEY 8e).  Inputs are resident in HBM before the timed region.  The forward is replayed from one hipGraph.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus:
+  "roofline":     the kernel with the largest share of device time (measured live with events on the launch stream in an
+                  eager pass of the same forward), algorithmic FLOPs or bytes / its summed duration vs peak;
+  "kernels":      the same figures for every C-ABI kernel, incl. the two the north_star names
+                  (mumpy_window_attention_fwd: MFMA; mumpy_deform_sample_fwd: HBM);
+  "cpu_baseline": the oracle (CPU restatement, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd"}
+GFLOP_PER_CLIP_T5 = 253.9         # whole-forward algorithmic work at T=5
+
+
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line is the only thing on stdout)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU (micro-batch)")
+    ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    return ap.parse_args()
+
+
+def profile_kernels(enc, dec, x):
+    """One eager forward with every C-ABI launch bracketed by events on its launch stream."""
+    from mumpy_hip import ops
+    with torch.no_grad():
+        dec(*enc(x))
+        torch.cuda.synchronize()
+        ops.PROFILE = {}
+        t0 = torch.cuda.Event(enable_timing=True)
+        t1 = torch.cuda.Event(enable_timing=True)
+        t0.record()
+        dec(*enc(x))
+        t1.record()
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+    total_ms = t0.elapsed_time(t1)
+    rows = []
+    for name, evs in prof.items():
+        ms = sum(a.elapsed_time(b) for a, b, _ in evs)
+        work = sum(w for _, _, w in evs)
+        row = {"kernel": name, "launches": len(evs), "ms": round(ms, 4), "avg_us": round(1e3 * ms / len(evs), 2)}
+        if work > 0 and ms > 0:
+            if name in HBM_BOUND:
+                ach = work / (ms * 1e-3) / 1e9
+                row.update(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4))
+            else:
+                ach = work / (ms * 1e-3) / 1e12
+                row.update(bound="mfma", achieved=round(ach, 2), peak=PEAK_F32_MFMA_TFLOPS, unit="TFLOP/s",
+                           frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4))
+        rows.append(row)
+    rows.sort(key=lambda r: -r["ms"])
+    return rows, total_ms
+
+
+def cpu_baseline(frames, sample_b):
+    """Oracle ('port' of the reference CPU path) on this box's host cores, bounded sample."""
+    from oracle import mumpy_oracle as O
+    from weight_fill import fill_state_dict_, seeded_randn
+    man_e = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_encoder_t5.json" if frames == 5 else "state_dict_encoder.json")))
+    man_d = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_decoder_t5.json" if frames == 5 else "state_dict_decoder.json")))
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    cores = max(1, min(cores, int(os.environ.get("MUMPY_CPU_THREADS", "16"))))   # a 1-GPU box's CPU share is 16 cores
+    torch.set_num_threads(cores)
+    log(f"  cpu baseline on {cores} threads")
+
+    def build(man):
+        from models.modules.swinTransformer import build_shift_mask, relative_position_index
+        sd = {}
+        for k, (shape, dt) in man.items():
+            if k.endswith("relative_position_index"):
+                sd[k] = relative_position_index(7, 7)
+            elif k.endswith("attn_mask"):
+                side = [56, 28, 14, 7][int(k.split("layers.layers.")[1].split(".")[0])]
+                sd[k] = build_shift_mask(49 * shape[0] // side, side, 7, 3)
+            else:
+                sd[k] = torch.zeros(shape, dtype=getattr(torch, dt))
+        return fill_state_dict_(sd)
+
+    sde, sdd = build(man_e), build(man_d)
+    x = seeded_randn(1234, sample_b, frames, 3, 224, 224)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.full_forward(sde, sdd, x[:1])                      # warm-up (thread pools, allocator)
+        log(f"  warm-up B=1 pass: {time.perf_counter() - t0:.2f} s")
+        ts = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            O.full_forward(sde, sdd, x)
+            ts.append(time.perf_counter() - t0)
+            log(f"  B={sample_b} pass: {ts[-1]:.2f} s")
+    t = min(ts)
+    return {"value": round(sample_b / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle full forward, B={sample_b}, T={frames}, 224x224 fp32, 1 warm-up (B=1) + 2 timed, best of 2 "
+                      f"({t:.2f} s per pass)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # RCCL over xGMI
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    from mumpy_hip import ops
+    from mumpy_hip.graph import GraphedForward
+    from weight_fill import fill_module_, seeded_randn
+
+    log("building model + synthetic weights")
+    enc = fill_module_(Encoder(num_frames=args.frames).eval()).to(dev)
+    dec = fill_module_(Decoder(input_token_temporal_dims=[1, 1, args.frames]).eval()).to(dev)
+    x = seeded_randn(1234 + rank, args.batch, args.frames, 3, 224, 224).to(dev)         # resident before timing
+    gt = (torch.rand(args.batch, 1, 224, 224, generator=torch.Generator().manual_seed(99 + rank)) < 0.1).to(dev)
+
+    log("warm-up (eager)")
+    with torch.no_grad():
+        for i in range(max(args.warmup, 1)):
+            fx, vx, dx = enc(x)
+            torch.cuda.synchronize()
+            if i == 0:
+                log("  first encoder forward done")
+            logits = dec(fx, vx, dx)[0]
+            torch.cuda.synchronize()
+            if i == 0:
+                log("  first decoder forward done")
+    log("capturing hipGraph")
+    fwd = None if args.no_graph else GraphedForward(enc, dec, x)
+    log("timing")
+
+    def step():
+        if fwd is None:
+            with torch.no_grad():
+                return dec(*enc(x))[0]
+        return fwd(x)[0]
+
+    for _ in range(2):
+        step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logits = step()
+    # eval tail on device (test.py:100-108) + the ONE collective of the path: all-reduce of the metric vector
+    pred = ops.sigmoid_threshold(logits)
+    inter = (pred.bool() & gt).flatten(1).sum(1).double()
+    union = (pred.bool() | gt).flatten(1).sum(1).double()
+    npix = float(pred[0].numel())
+    recall = inter / (gt.flatten(1).sum(1).double() + 1e-6 * npix)
+    precision = inter / (pred.flatten(1).sum(1).double() + 1e-6)
+    f1 = 2 * precision * recall / (precision + recall + 1e-6)
+    metric = torch.stack([f1.sum(), ((inter + 1e-5) / (union + 1e-5)).sum(),
+                          torch.tensor(float(args.batch), device=dev, dtype=torch.float64)])
+    if world > 1:
+        dist.all_reduce(metric)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        log(f"timed: {1e3 * dt / args.steps:.2f} ms/step; profiling kernels")
+        kernels, eager_ms = profile_kernels(enc, dec, x)
+        dom = dict(kernels[0])
+        dom["traffic"] = None
+        dom.pop("launches", None)
+        dom.pop("ms", None)
+        clips = args.batch * world * args.steps
+        out = {
+            "metric": "clips/sec fwd (B=8,T=5,224x224)", "value": round(clips / dt, 3), "unit": "clips/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"full Mumpy forward (3 temporal views, pyramid decoder), B={args.batch} clips/GPU, "
+                                   f"T={args.frames}, 224x224, fp32, tubelets ({args.frames},{args.frames - 1},1)",
+                       "global_batch": args.batch * world, "launch": "eager" if fwd is None else "hipGraph replay",
+                       "parallelism": f"batch-sharded x{world}, one metric all-reduce"},
+            "roofline": dom,
+            "kernels": kernels,
+            "forward_gflop_per_clip": GFLOP_PER_CLIP_T5 if args.frames == 5 else None,
+            "whole_forward_frac_of_f32_mfma_peak": round(GFLOP_PER_CLIP_T5 * 1e9 * clips / dt / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)
+            if args.frames == 5 else None,
+            "eager_forward_ms": round(eager_ms, 3),
+            "eval_metric": {"f1": float(metric[0] / metric[2]), "iou": float(metric[1] / metric[2]), "clips": int(metric[2])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            log("cpu baseline (oracle on host cores)")
+            out["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_sample_batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -125,6 +125,7 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 
 extern "C" int mumpy_linear_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
                                 int64_t M, int N, int K, int act, void* stream) {
+    if (M == 0) return 0;      // empty batch
     MUMPY_REQUIRE(x && W && y, MUMPY_ENULL, "linear: null pointer");
     MUMPY_REQUIRE(aligned16(x) && aligned16(W) && aligned16(y) && aligned16(residual), MUMPY_EALIGN,
                   "linear: pointers must be 16-byte aligned");

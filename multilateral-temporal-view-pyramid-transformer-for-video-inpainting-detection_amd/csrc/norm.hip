@@ -93,6 +93,7 @@ bool pick_split(int C, int* lpr, int* nv) {
 
 extern "C" int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, int64_t rows,
                                    int C, float eps, void* stream) {
+    if (rows == 0) return 0;   // empty batch: nothing to do, pointers may be null
     MUMPY_REQUIRE(x && gamma && beta && y, MUMPY_ENULL, "layernorm: null pointer");
     MUMPY_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), MUMPY_EALIGN,
                   "layernorm: pointers must be 16-byte aligned");

@@ -323,15 +323,34 @@ def test_strict_checkpoint_roundtrip(tmp_path, model_t3):
 
 
 def test_hip_graph_replay_is_identical(model_t3):
-    """The whole forward is capturable into one hipGraph (no allocation, sync or host round trip inside)."""
+    """The whole forward is capturable into one hipGraph (no allocation, sync or host round trip inside).
+    Encoder outputs (all hand-written kernels) must replay bit for bit; the decoder's MIOpen convolutions are not
+    run-to-run deterministic even in eager mode (atomics), so logits are compared to round-off."""
     from mumpy_hip.graph import GraphedForward
     enc, dec = model_t3
-    x = seeded_randn(78, 1, 3, 3, 224, 224).to(DEV)
+    for seed in (78, 79):
+        x = seeded_randn(seed, 1, 3, 3, 224, 224).to(DEV)
+        with torch.no_grad():
+            fx, vx, dx = enc(x)
+            eager = dec(fx, vx, dx)[0].clone()
+            fx2 = enc(x)[0]
+        assert torch.equal(fx, fx2)                               # eager determinism of the HIP kernels
+        if seed == 78:
+            g = GraphedForward(enc, dec, x)
+        assert rel_err(g(x)[0].cpu(), eager.cpu()) < 1e-5
+
+
+def test_encoder_graph_replay_bit_exact(model_t3):
+    enc, _ = model_t3
+    x = seeded_randn(80, 2, 3, 3, 224, 224).to(DEV)
     with torch.no_grad():
-        eager = dec(*enc(x))[0].clone()
-    g = GraphedForward(enc, dec, x)
-    assert torch.equal(g(x)[0], eager)
-    x2 = seeded_randn(79, 1, 3, 3, 224, 224).to(DEV)
-    with torch.no_grad():
-        eager2 = dec(*enc(x2))[0]
-    assert torch.equal(g(x2)[0], eager2)
+        fx, vx, dx = enc(x)
+        fx, dx = fx.clone(), dx.clone()
+        static = x.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            gfx, gvx, gdx = enc(static)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gfx, fx) and torch.equal(gdx, dx)
+    assert all(torch.equal(a, b) for sa, sb in zip(gvx, vx) for a, b in zip(sa, sb))
