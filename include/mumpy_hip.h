@@ -51,6 +51,14 @@ int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, f
 int mumpy_linear_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
                      int64_t M, int N, int K, int act, void* stream);
 
+/* Same, with a caller-owned scratch buffer that lets small-M / deep-K shapes split K across workgroups (partial sums
+ * to the scratch slab, combined in a fixed order by a second kernel: bitwise reproducible).  Size it with
+ * mumpy_linear_workspace_bytes(M,N,K) (0 = this shape does not split); a NULL / too-small workspace just disables
+ * the split.  The workspace must not be shared by launches that may overlap. */
+int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K);
+int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
+                        int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Swin window attention core  — swin:54-83 (partition/reverse), 273,295 (roll), 145-163 (softmax(QK^T)V)
  * qkv:  (B, Hs*W, 3*C) raster token order over the stacked grid Hs = t*H rows by W columns; channel
  *       layout [q|k|v][head][32] exactly as nn.Linear(C,3C) emits it (swin:142).

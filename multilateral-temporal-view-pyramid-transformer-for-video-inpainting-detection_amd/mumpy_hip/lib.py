@@ -16,6 +16,8 @@ c_fl = ctypes.c_float
 SIGNATURES = {
     "mumpy_layernorm_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_fl, c_f],
     "mumpy_linear_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f],
+    "mumpy_linear_ws_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
+    "mumpy_linear_workspace_bytes": [c_l, c_i, c_i],
     "mumpy_window_attention_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_deform_offsets_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_sample_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
@@ -62,6 +64,6 @@ def load_library():
     for name, args in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError here = the library is stale: fail loudly
         fn.argtypes = args
-        fn.restype = c_i
+        fn.restype = c_l if name.endswith("_bytes") else c_i
     _LIB = lib
     return lib

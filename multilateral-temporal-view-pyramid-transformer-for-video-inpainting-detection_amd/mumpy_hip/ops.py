@@ -8,6 +8,7 @@ import torch
 from .lib import load_library
 
 ACT_NONE, ACT_GELU = 0, 1
+_WS_BYTES = {}
 NEG = -1e30
 
 
@@ -74,8 +75,13 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
         residual = _chk(residual, "residual")
         if residual.numel() != m * n:
             raise RuntimeError("linear: residual shape mismatch")
-    _call("mumpy_linear_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out),
-          m, n, k, act, _stream(), work=2.0 * m * n * k)
+    key = (m, n, k)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
+    ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None   # split-K slab (small-M shapes)
+    _call("mumpy_linear_ws_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
+          _p(out), m, n, k, act, _p(ws), wsb, _stream(), work=2.0 * m * n * k)
     return out
 
 

@@ -13,7 +13,7 @@ def header_decls():
     src = open(os.path.join(ROOT, "include", "mumpy_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|const char\*)\s+(mumpy_\w+)\s*\(([^)]*)\)\s*;", src):
+    for m in re.finditer(r"\b(?:int64_t|int|const char\*)\s+(mumpy_\w+)\s*\(([^)]*)\)\s*;", src):
         args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
         decls[m.group(1)] = args
     return decls

@@ -46,7 +46,7 @@ def test_layernorm_empty_and_inplace():
 
 
 @pytest.mark.parametrize("m,n,k", [(392, 96, 96), (1, 128, 32), (129, 288, 96), (1568, 384, 1536), (300, 768, 2560),
-                                   (257, 2304, 768), (1000, 512, 128), (64, 96, 384), (131, 192, 384), (50, 3072, 768)])
+                                   (257, 2304, 768), (1000, 512, 128), (64, 96, 384), (131, 192, 384), (50, 3072, 768), (392, 768, 3072), (1568, 384, 1536), (392, 256, 12800), (1960, 768, 3072), (7840, 512, 2048)])
 @pytest.mark.parametrize("act,res", [(0, False), (1, True)])
 def test_linear(m, n, k, act, res):
     x, w, b = seeded_randn(m, m, k), seeded_randn(n, n, k) / k ** 0.5, seeded_randn(k, n)
