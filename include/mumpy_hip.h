@@ -59,6 +59,14 @@ int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
                         int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Same, with the rows of x grouped in blocks: row m lives at x + (m / rows_per_block) * block_stride +
+ * (m % rows_per_block) * K (floats).  Feeds one time slice of the (B, T*n, C) view-3 tokens to the decoder's
+ * Conv3d(k=(T,1,1)) heads (decoder.py:98-120) as a (B*n, C) operand without the merge/permute copy of decoder.py:43-53;
+ * the T slices are chained through `residual`. */
+int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, const float* W,
+                          const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                          void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Swin window attention core  — swin:54-83 (partition/reverse), 273,295 (roll), 145-163 (softmax(QK^T)V)
  * qkv:  (B, Hs*W, 3*C) raster token order over the stacked grid Hs = t*H rows by W columns; channel
  *       layout [q|k|v][head][32] exactly as nn.Linear(C,3C) emits it (swin:142).
@@ -130,6 +138,26 @@ int mumpy_patch_merge_ln_fwd(const float* x, const float* gamma, const float* be
  * qkv: (S, T, 3*C) with S = B*49 spatial sites, heads of width 64; out: (S, T, C).  T <= 16. */
 int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T, int C, int heads,
                                  float scale, void* stream);
+
+/* ---- Decoder glue in NHWC (decoder.py:67-225): everything between two convolutions ---------------------------
+ * gn_stats: x (B,HW,C) NHWC -> partial (B, nsplit, G, 2) = per-slice {sum, sum of squares} of each GroupNorm group
+ * (nn.GroupNorm statistics, decoder.py:70,77,84,91,101-119,151-180), combined in fixed order by gn_apply. */
+int mumpy_gn_stats_nhwc_fwd(const float* x, float* partial, int B, int64_t HW, int C, int G, int nsplit,
+                            void* stream);
+
+/* gn_apply_resample: out = epilogue( resample( mean4( act( GroupNorm(x) ) ) ) ), one pass, NHWC.
+ *   partial/gamma/beta/G/eps: GroupNorm (partial == NULL: no normalisation, pure resample);
+ *   act: 0 none, 1 ReLU, 2 Sigmoid;  mean4: 1 = PixelShuffle(2)+AvgPool(2) == mean over channel quadruples
+ *   (DAP, decoder.py:140-143; commutes with the bilinear upsample);  scale 1|2|4 bilinear, align_corners as in
+ *   nn.Upsample (True: decoder.py:72-93; False: decoder.py:10,136-137);
+ *   ep_mode 0: none, 1: + ep_a*ep_b (decoder.py:219-220), 2: * ep_a (decoder.py:221, 14), operands dense
+ *   (B,Ho,Wo,Cout);  out: (B,Ho,Wo,out_ctot) written at channel offset out_coff (lets a torch.cat operand be
+ *   produced in place, decoder.py:210,213).  C <= 256. */
+int mumpy_gn_apply_resample_nhwc_fwd(const float* x, const float* partial, int nsplit, const float* gamma,
+                                     const float* beta, int G, float eps, int act, int mean4, int scale,
+                                     int align_corners, int ep_mode, const float* ep_a, const float* ep_b,
+                                     float* out, int out_ctot, int out_coff, int B, int H, int W, int C,
+                                     void* stream);
 
 /* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
 int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);

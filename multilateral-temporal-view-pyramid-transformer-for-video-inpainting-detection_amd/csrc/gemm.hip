@@ -22,7 +22,7 @@ template <int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, const float* residual,
                                                      float* Y, int64_t M, int N, int K, int act, unsigned gn,
-                                                     int ksplit, float* slab) {
+                                                     int ksplit, float* slab, int64_t rpb, int64_t bstride) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
@@ -47,12 +47,18 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
     f32x4 areg[A_LD], breg[B_LD];
 
+    // A rows may be strided in blocks (rows m of block m / rpb start at X + (m / rpb) * bstride): lets a caller feed
+    // (B, t, n, C) tokens of one time slice as an (B*n, C) operand without a copy.  Dense: rpb = M.
+    const float* arow[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int64_t m = m0 + ld_row + 32 * i;
+        arow[i] = (m < M) ? X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4 : nullptr;
+    }
     auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int64_t m = m0 + ld_row + 32 * i;
-            areg[i] = (m < M) ? *reinterpret_cast<const f32x4*>(X + m * K + k0 + 4 * ld_c4) : f32x4{0, 0, 0, 0};
-        }
+        for (int i = 0; i < A_LD; ++i)
+            areg[i] = arow[i] ? *reinterpret_cast<const f32x4*>(arow[i] + k0) : f32x4{0, 0, 0, 0};
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             const int n = n0 + ld_row + 32 * i;
@@ -191,14 +197,15 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split) {
 }
 
 int launch_linear(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
-                  int K, int act, float* ws, int64_t ws_bytes, hipStream_t s) {
+                  int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0) {
+    if (rpb <= 0) { rpb = M; bstride = 0; }
     Plan p = make_plan(M, N, K, ws != nullptr);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
 #define MUMPY_GEMM(BM_, BN_, WM_, WN_)                                                                               \
     hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, bias, residual, \
-                       y, M, N, K, act, p.gn, p.ksplit, ws)
+                       y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride)
     if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 64);
     else if (p.tile == 1) MUMPY_GEMM(128, 96, 32, 96);
     else MUMPY_GEMM(64, 64, 32, 32);
@@ -249,4 +256,16 @@ extern "C" int mumpy_linear_ws_fwd(const float* x, const float* W, const float* 
     MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "linear: workspace must be 16-byte aligned");
     return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream));
+}
+
+extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, const float* W,
+                                     const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M == 0) return 0;
+    if (int rc = check_linear_args(x, W, residual, y, M, N, K, act)) return rc;
+    MUMPY_REQUIRE(rows_per_block > 0 && M % rows_per_block == 0 && block_stride % 4 == 0, MUMPY_EINVAL,
+                  "linear_rows: M=%lld must be a multiple of rows_per_block=%lld and block_stride %% 4 == 0",
+                  (long long)M, (long long)rows_per_block);
+    return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
+                         workspace ? workspace_bytes : 0, as_stream(stream), rows_per_block, block_stride);
 }

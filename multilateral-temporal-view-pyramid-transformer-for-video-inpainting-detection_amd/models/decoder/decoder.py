@@ -1,12 +1,18 @@
 """Multi-pyramid decoder — drop-in for the reference's models/decoder/decoder.py (`Decoder`), same constructor
 defaults and the same 92 state_dict keys (nn.Sequential indices included).
 
-Round-1 status: the decoder is 8 % of the forward's FLOPs, all of it dense convolution.  Its graph is
-restated here without the reference's intermediate lists; convolutions / GroupNorm / resampling run as PyTorch-ROCm
-GPU ops (MIOpen) on the same stream — they are captured in the same hipGraph as the encoder's HIP kernels.  The
-temporal Conv3d(k=(T,1,1)) heads are NOT convolutions at all (kernel = stride = full extent): they are per-pixel
-Linears over the (C,T) axis and run on mumpy_linear_fwd straight from the encoder's token-major stage outputs, so the
-(B,C',T,h,h) merged tensor of decoder.py:43-53 is never built.
+Execution: the decoder is NHWC (torch.channels_last) end to end.
+  * The four temporal heads Conv3d(C', 256, k=s=(T,1,1)) are not convolutions (kernel = stride = full extent) but
+    per-pixel Linears over (C', T).  They run on the fp32 MFMA GEMM straight from the encoder's token-major stage
+    outputs: views 1/2 are repeated over time by the reference (decoder.py:50), so their T weight slices are summed once
+    and applied in one GEMM each; view 3 contributes T GEMMs over strided time slices chained through the residual
+    input.  The (B,C',T,h,h) merged tensor of decoder.py:43-53 and its permute are never built; FLOPs drop ~2x.
+  * Everything between two convolutions — GroupNorm, ReLU/Sigmoid, DAP (PixelShuffle+AvgPool == 4-channel mean),
+    bilinear x2/x4 (both align_corners modes), the "+ gcn*freq" / "* freq" / SEB multiply — is two hand-written
+    kernels (mumpy_gn_stats_nhwc_fwd, mumpy_gn_apply_resample_nhwc_fwd).  decoder_5's (B,128,224,224) output and
+    DAP's (B,32,448,448) intermediate are never formed.
+  * The spatial convolutions themselves (3x3, 7x1, 1x7; 8 % of the forward's FLOPs) still run on MIOpen via torch,
+    NHWC, on the same stream and inside the same hipGraph.  Returned tensors are logical NCHW with NHWC strides.
 """
 import torch
 import torch.nn as nn
@@ -85,10 +91,10 @@ class Decoder(nn.Module):
         self.decoder_frequency_2 = _freq_block(wide, wide, 8)
         self.decoder_frequency_3 = _freq_block(wide, num_classes, 4)
         self.decoder_frequency_4 = _freq_block(num_classes, wide, 8)
-        self._rgbw = [Derived() for _ in range(4)]
+        self._derived = {}
 
     def merge_views_along_channel_axis(self, tokens, height):
-        """API parity with decoder.py:43-53: [(B,t,n,C_v)] -> (B, sum C, Tmax, h, h)."""
+        """API parity with decoder.py:43-53: [(B,t,n,C_v)] -> (B, sum C, Tmax, h, h).  Not used by forward()."""
         tmax = max(self.input_token_temporal_dims)
         parts = []
         for v, x in enumerate(tokens):
@@ -100,41 +106,92 @@ class Decoder(nn.Module):
         b, t, n, c = m.shape
         return m.reshape(b, t, height, n // height, c).permute(0, 4, 1, 2, 3)
 
+    # ------------------------------------------------------------------------------------------------ helpers
+    def _cached(self, key, sources, fn):
+        d = self._derived.get(key)
+        if d is None:
+            d = self._derived[key] = Derived()
+        return d.get(sources, fn)
+
+    def _conv(self, x, conv):
+        """MIOpen convolution, NHWC in / NHWC out; the channels_last weight copy is cached per weight version."""
+        w = self._cached(("w", id(conv)), (conv.weight,), lambda: conv.weight.contiguous(memory_format=torch.channels_last))
+        return F.conv2d(x, w, conv.bias, padding=conv.padding)
+
+    def _gcm(self, m, x):
+        return self._conv(self._conv(x, m.conv_l1), m.conv_l2) + self._conv(self._conv(x, m.conv_r1), m.conv_r2)
+
+    @staticmethod
+    def _gn(x, gn):
+        x, partial, nsplit = ops.gn_stats(x, gn.num_groups)
+        return x, (partial, nsplit, gn.weight, gn.bias, gn.num_groups, gn.eps)
+
     def _rgb_head(self, idx, stage_views, side):
-        """Conv3d(C', 256, k=s=(T,1,1)) over the channel-merged views == per-pixel Linear with K = C'*T.
-        Token-major operand X[b, n, (t, c)] is assembled directly from the three stage outputs."""
+        """Conv3d(C', 256, k=s=(T,1,1)) + GroupNorm(16) + ReLU on the channel-merged, time-repeated views."""
         tmax = max(self.input_token_temporal_dims)
-        conv, gn = getattr(self, f"rgb_decoder_{idx + 1}")[0], getattr(self, f"rgb_decoder_{idx + 1}")[1]
-        cols = []
+        seq = getattr(self, f"rgb_decoder_{idx + 1}")
+        conv, gn = seq[0], seq[1]
+        w = conv.weight                                               # (256, C1+C2+C3, T, 1, 1)
+        y, c0 = None, 0
         for v, x in enumerate(stage_views):
-            b, t, n, c = x.shape
+            b, t, l, c = x.shape
             tv = self.input_token_temporal_dims[v]
-            x = x.reshape(b, tv, (t * n) // tv, c)
-            cols.append(x.expand(b, tmax, x.shape[2], c) if tv == 1 else x.repeat(1, tmax // tv, 1, 1))
-        m = torch.cat(cols, dim=-1)                                   # (B,T,n,C')
-        b, t, n, c = m.shape
-        xm = m.permute(0, 2, 1, 3).reshape(b * n, t * c)              # k = t*C' + c
-        w = conv.weight                                               # (256, C', T, 1, 1)
-        wk = self._rgbw[idx].get((w,), lambda: w.reshape(w.shape[0], c, t).permute(0, 2, 1).reshape(w.shape[0], t * c).contiguous())
-        y = ops.linear(xm, wk, conv.bias)                             # (B*n, 256)
-        y = y.reshape(b, side, side, -1).permute(0, 3, 1, 2)
-        return F.relu(F.group_norm(y, gn.num_groups, gn.weight, gn.bias, gn.eps))
+            n = (t * l) // tv
+            if tv == 1:       # same tokens at every time step -> one GEMM with the T weight slices summed
+                wv = self._cached(("h", idx, v), (w,), lambda: w[:, c0:c0 + c, :, 0, 0].sum(2).contiguous())
+                y = ops.linear(x.reshape(b * n, c), wv, conv.bias if y is None else None, residual=y)
+            elif tv == tmax:  # one GEMM per time slice over the strided (B, n, C) view, accumulated via the residual
+                xv = x.reshape(b, tv, n, c)
+                for tt in range(tv):
+                    wt = self._cached(("h", idx, v, tt), (w,), lambda: w[:, c0:c0 + c, tt, 0, 0].contiguous())
+                    y = ops.linear_rows(xv[:, tt], wt, conv.bias if y is None else None, residual=y)
+            else:
+                raise NotImplementedError("views must have temporal dim 1 or max (true for every Mumpy config)")
+            c0 += c
+        y = y.reshape(b, side, side, -1).permute(0, 3, 1, 2)          # logical NCHW over NHWC memory
+        y, g = self._gn(y, gn)
+        return ops.gn_apply_resample(y, g, act=ops.ACT_RELU)
+
+    def _freq(self, seq, x):
+        x = self._conv(F.avg_pool2d(x, 2), seq[1])
+        x, g = self._gn(x, seq[2])
+        return ops.gn_apply_resample(x, g, act=ops.ACT_SIGMOID)
+
+    def _up(self, x, scale, out=None, out_coff=0):                     # nn.Upsample(bilinear, align_corners=False)
+        return ops.gn_apply_resample(x, None, scale=scale, align_corners=False, out=out, out_coff=out_coff)
+
+    def _seb(self, m, x1, x2):                                         # x1 * upsample(conv(x2))  (decoder.py:12-14)
+        return ops.gn_apply_resample(self._conv(x2, m.conv), None, scale=2, align_corners=False, ep_mode=ops.EP_MUL, ep_a=x1)
+
+    def _dec(self, seq, x, ep_mode=0, ep_a=None, ep_b=None, mean4=False):
+        """conv3x3 -> GroupNorm(8) -> ReLU -> bilinear x2 (align_corners=True) [-> DAP] [-> epilogue]."""
+        x, g = self._gn(self._conv(x, seq[0]), seq[1])
+        return ops.gn_apply_resample(x, g, act=ops.ACT_RELU, mean4=mean4, scale=2, align_corners=True, ep_mode=ep_mode,
+                                     ep_a=ep_a, ep_b=ep_b)
 
     def forward(self, x, view_x, ffinfo):
         """x (B,2304,7,7), view_x[4][3] of (B,1,L,C), ffinfo (B,9,224,224) -> (logits (B,1,224,224), feats (B,32,224,224))."""
         rgb1, rgb2, rgb3, rgb4 = [self._rgb_head(i, view_x[i], self.shape[i]) for i in range(4)]
-        freq0 = self.decoder_frequency_0(ffinfo)
-        freq1 = self.decoder_frequency_1(freq0)
-        freq2 = self.decoder_frequency_2(freq1)
-        freq3 = self.decoder_frequency_3(freq2)
-        freq4 = self.decoder_frequency_4(freq3)
-        out1 = self.ecre(self.gcm1(torch.cat([rgb4, x], dim=1)) * freq4)
-        gcn1 = self.gcm2(self.seb1([rgb3, rgb4]))
-        gcn2 = self.gcm3(self.seb2([rgb2, torch.cat([rgb3, self.upsample2(rgb4)], dim=1)]))
-        gcn3 = self.gcm4(self.seb3([rgb1, torch.cat([rgb2, self.upsample2(rgb3), self.upsample4(rgb4)], dim=1)]))
-        z = self.decoder_2(gcn1 * freq3 + out1)
-        z = self.decoder_3(z + gcn2 * freq2)
-        z = self.decoder_4(z + gcn3 * freq1)
-        z = self.decoder_5(z * freq0)
-        x_feats = self.DAP(z)
-        return self.final_out(x_feats), x_feats
+        b, dev = x.shape[0], x.device
+        freq0 = self._freq(self.decoder_frequency_0, ffinfo.contiguous(memory_format=torch.channels_last))
+        freq1 = self._freq(self.decoder_frequency_1, freq0)
+        freq2 = self._freq(self.decoder_frequency_2, freq1)
+        freq3 = self._freq(self.decoder_frequency_3, freq2)
+        freq4 = self._freq(self.decoder_frequency_4, freq3)
+        x = x.contiguous(memory_format=torch.channels_last)
+        out1 = self.ecre(self._gcm(self.gcm1, torch.cat([rgb4, x], dim=1)) * freq4)
+        gcn1 = self._gcm(self.gcm2, self._seb(self.seb1, rgb3, rgb4))
+        cat2 = ops.empty_nhwc(b, 512, 14, 14, dev)                     # [rgb3 | up2(rgb4)]          (decoder.py:210)
+        cat2[:, :256] = rgb3
+        self._up(rgb4, 2, out=cat2, out_coff=256)
+        gcn2 = self._gcm(self.gcm3, self._seb(self.seb2, rgb2, cat2))
+        cat3 = ops.empty_nhwc(b, 768, 28, 28, dev)                     # [rgb2 | up2(rgb3) | up4(rgb4)] (decoder.py:213)
+        cat3[:, :256] = rgb2
+        self._up(rgb3, 2, out=cat3, out_coff=256)
+        self._up(rgb4, 4, out=cat3, out_coff=512)
+        gcn3 = self._gcm(self.gcm4, self._seb(self.seb3, rgb1, cat3))
+        z = self._dec(self.decoder_2, gcn1 * freq3 + out1, ops.EP_ADD_MUL, gcn2, freq2)     # = decoder_3's input
+        z = self._dec(self.decoder_3, z, ops.EP_ADD_MUL, gcn3, freq1)                       # = decoder_4's input
+        z = self._dec(self.decoder_4, z, ops.EP_MUL, freq0)                                 # = decoder_5's input
+        x_feats = self._dec(self.decoder_5, z, mean4=True)                                  # DAP folded in
+        return self._conv(x_feats, self.final_out), x_feats

@@ -85,6 +85,85 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
     return out
 
 
+def linear_rows(x_view, weight, bias=None, residual=None, out=None):
+    """Linear over a (nblk, rows, K) VIEW whose rows are contiguous but whose blocks are strided (no copy)."""
+    if not x_view.is_cuda or x_view.dtype != torch.float32:
+        raise RuntimeError("mumpy_hip: linear_rows needs a float32 GPU tensor (there is no CPU path)")
+    nblk, rows, k = x_view.shape
+    if x_view.stride(2) != 1 or x_view.stride(1) != k:
+        raise RuntimeError("linear_rows: rows of a block must be contiguous")
+    weight = _chk(weight, "weight")
+    n = weight.shape[0]
+    m = nblk * rows
+    if out is None:
+        out = torch.empty(m, n, device=x_view.device, dtype=torch.float32)
+    key = (m, n, k)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
+    ws = torch.empty(wsb // 4, device=x_view.device, dtype=torch.float32) if wsb else None
+    _call("mumpy_linear_rows_fwd", x_view.data_ptr(), rows, x_view.stride(0), _p(weight),
+          _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out), m, n, k, ACT_NONE, _p(ws), wsb, _stream(),
+          work=2.0 * m * n * k)
+    return out
+
+
+def _nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
+    """Logical (B,C,H,W) tensor whose memory is NHWC (torch.channels_last)."""
+    if not t.is_cuda:
+        raise RuntimeError(f"mumpy_hip: {name} is on {t.device}; the HIP kernels need a GPU tensor (there is no CPU path)")
+    if t.dtype != torch.float32 or t.dim() != 4:
+        raise RuntimeError(f"mumpy_hip: {name} must be a 4-D float32 tensor")
+    b, c, h, w = t.shape
+    if t.stride() != (h * w * c, 1, w * c, c):
+        t = t.contiguous(memory_format=torch.channels_last)
+        if t.stride() != (h * w * c, 1, w * c, c):           # degenerate sizes: force the exact NHWC strides
+            t = t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+    return t
+
+
+def empty_nhwc(b, c, h, w, device):
+    return torch.empty(b, h, w, c, device=device, dtype=torch.float32).permute(0, 3, 1, 2)
+
+
+ACT_RELU, ACT_SIGMOID = 1, 2
+EP_NONE, EP_ADD_MUL, EP_MUL = 0, 1, 2
+
+
+def gn_stats(x, groups):
+    """x: logical (B,C,H,W), NHWC memory -> (partial, nsplit)."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    nsplit = max(1, min(64, (h * w * c) // 65536))
+    partial = torch.empty(b, nsplit, groups, 2, device=x.device, dtype=torch.float32)
+    _call("mumpy_gn_stats_nhwc_fwd", _p(x), _p(partial), b, h * w, c, groups, nsplit, _stream(), work=4.0 * x.numel())
+    return x, partial, nsplit
+
+
+def gn_apply_resample(x, gn=None, act=0, mean4=False, scale=1, align_corners=False, ep_mode=0, ep_a=None, ep_b=None,
+                      out=None, out_coff=0):
+    """x logical (B,C,H,W) NHWC.  gn = (partial, nsplit, gamma, beta, groups, eps) or None.  Returns logical NCHW / NHWC memory."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    cout = c // 4 if mean4 else c
+    ho, wo = h * scale, w * scale
+    if out is None:
+        out = empty_nhwc(b, cout, ho, wo, x.device)
+    else:
+        assert out.shape[0] == b and out.shape[2] == ho and out.shape[3] == wo and out.stride(1) == 1
+    if ep_a is not None:
+        ep_a = _nhwc(ep_a, "ep_a")
+        assert tuple(ep_a.shape) == (b, cout, ho, wo), "epilogue operand shape"
+    if ep_b is not None:
+        ep_b = _nhwc(ep_b, "ep_b")
+        assert tuple(ep_b.shape) == (b, cout, ho, wo), "epilogue operand shape"
+    partial, nsplit, gamma, beta, groups, eps = gn if gn is not None else (None, 0, None, None, 1, 0.0)
+    _call("mumpy_gn_apply_resample_nhwc_fwd", _p(x), _p(partial), nsplit, _p(gamma), _p(beta), groups, eps, act,
+          1 if mean4 else 0, scale, 1 if align_corners else 0, ep_mode, _p(ep_a), _p(ep_b), _p(out), out.shape[1], out_coff,
+          b, h, w, c, _stream(), work=4.0 * (x.numel() + b * cout * ho * wo))
+    return out
+
+
 def add(a, b, out=None):
     a, b = _chk(a, "a"), _chk(b, "b")
     out = torch.empty_like(a) if out is None else out

@@ -230,6 +230,65 @@ def test_tokenizer_long_tubelet_t9():
         assert rel_err(y.cpu(), r) < TIGHT
 
 
+# ------------------------------------------------------------------ decoder glue kernels (NHWC)
+@pytest.mark.parametrize("c,g,h", [(128, 8, 14), (256, 16, 7), (32, 4, 14), (128, 8, 56), (256, 16, 28)])
+@pytest.mark.parametrize("act", [1, 2])
+def test_groupnorm_act(c, g, h, act):
+    x = seeded_randn(c + h, 2, c, h, h) * 2 + 0.5
+    gam, bet = seeded_randn(1, c), seeded_randn(2, c)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    xn, partial, nsplit = ops.gn_stats(xd, g)
+    y = ops.gn_apply_resample(xn, (partial, nsplit, gam.to(DEV), bet.to(DEV), g, 1e-5), act=act)
+    ref = F.group_norm(x.double(), g, gam.double(), bet.double(), 1e-5)
+    ref = F.relu(ref) if act == 1 else torch.sigmoid(ref)
+    assert y.shape == ref.shape
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize("scale,align", [(2, True), (2, False), (4, False)])
+def test_bilinear_resample_modes(scale, align):
+    x = seeded_randn(scale, 2, 64, 14, 14)
+    y = ops.gn_apply_resample(x.to(DEV).contiguous(memory_format=torch.channels_last), None, scale=scale, align_corners=align)
+    ref = F.interpolate(x.double(), scale_factor=scale, mode="bilinear", align_corners=align)
+    assert rel_err(y.cpu(), ref) < 1e-5      # fp32 source-index scale (in-1)/(out-1), as torch computes it
+
+
+def test_decoder_tail_fusion():
+    """conv output -> GN(8) -> ReLU -> x2 (align_corners=True) -> PixelShuffle(2) -> AvgPool(2), and the epilogues."""
+    x = seeded_randn(5, 2, 128, 28, 28)
+    gam, bet = seeded_randn(6, 128), seeded_randn(7, 128)
+    a, b = seeded_randn(8, 2, 128, 56, 56), seeded_randn(9, 2, 128, 56, 56)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    xn, partial, nsplit = ops.gn_stats(xd, 8)
+    gn = (partial, nsplit, gam.to(DEV), bet.to(DEV), 8, 1e-5)
+    up = F.interpolate(F.relu(F.group_norm(x.double(), 8, gam.double(), bet.double(), 1e-5)), scale_factor=2,
+                       mode="bilinear", align_corners=True)
+    y = ops.gn_apply_resample(xn, gn, act=1, mean4=True, scale=2, align_corners=True)
+    assert rel_err(y.cpu(), F.avg_pool2d(F.pixel_shuffle(up, 2), 2)) < 1e-5
+    y = ops.gn_apply_resample(xn, gn, act=1, scale=2, align_corners=True, ep_mode=ops.EP_ADD_MUL, ep_a=a.to(DEV), ep_b=b.to(DEV))
+    assert rel_err(y.cpu(), up + a.double() * b.double()) < 1e-5
+    y = ops.gn_apply_resample(xn, gn, act=1, scale=2, align_corners=True, ep_mode=ops.EP_MUL, ep_a=a.to(DEV))
+    assert rel_err(y.cpu(), up * a.double()) < 1e-5
+    cat = ops.empty_nhwc(2, 384, 56, 56, DEV)
+    cat.zero_()
+    ops.gn_apply_resample(xn, None, scale=2, align_corners=False, out=cat, out_coff=256)
+    assert rel_err(cat[:, 256:].cpu(), F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)) < 1e-6
+    assert float(cat[:, :256].abs().max()) == 0.0
+
+
+def test_linear_rows_strided_time_slices():
+    """One time slice of (B, T, n, C) tokens as a (B*n, C) GEMM operand without a copy, chained via the residual."""
+    b, t, n, c, nout = 3, 5, 196, 128, 256
+    x = seeded_randn(1, b, t, n, c)
+    w = seeded_randn(2, nout, c, t) / (c * t) ** 0.5
+    bias = seeded_randn(3, nout)
+    xd, y = x.to(DEV), None
+    for tt in range(t):
+        y = ops.linear_rows(xd[:, tt], w[:, :, tt].contiguous().to(DEV), bias.to(DEV) if tt == 0 else None, residual=y)
+    ref = torch.einsum("btnc,oct->bno", x.double(), w.double()).reshape(b * n, nout) + bias.double()
+    assert rel_err(y.cpu(), ref) < 1e-5
+
+
 def test_sigmoid_threshold():
     z = seeded_randn(4, 2, 1, 224, 224)
     z[0, 0, 0, :4] = torch.tensor([0.0, 1e-7, -1e-7, 30.0])
