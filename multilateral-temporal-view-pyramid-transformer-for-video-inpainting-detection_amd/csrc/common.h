@@ -45,7 +45,20 @@ __device__ __forceinline__ float wave_sum(float v, int width) {
     return v;
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 fma instead of
+// libm erff's ~40-instruction piecewise path -- the GELU epilogue of the fc1 GEMMs is VALU-bound otherwise.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
 
 // raster token of in-window position p of window (wy,wx) on a (Hs,W) grid after roll(-shift)
 // (swin:54-66 + 273): shifted[y][x] = src[(y+shift)%Hs][(x+shift)%W].

@@ -5,11 +5,15 @@
 // read the same way: lane (r = lane&31, h = lane>>5) owns row r of a 32-row tile and, per 32-deep K chunk, the 16
 // consecutive k's [16h, 16h+16) -> four ds_read_b128; k-slot h of MFMA step s is k = 16h+s for A and B alike.
 //
-// Block = 4 waves, tile BM x BN x 32, LDS rows padded to 36 dwords (16 consecutive rows hit 16 distinct 16-B slots
-// of the 64-bank row: conflict-free ds_read_b128), two LDS buffers, next chunk's global loads (16 B per lane, 128-B
-// row segments) in flight under the MFMAs, one barrier per chunk.  Two tile shapes cover every N of the model
-// exactly: 128x128 (waves 2x2, 64x64 each) and 128x96 (waves 4x1, 32x96 each) for the 96*2^s widths of views 1/2.
+// Tiles: 128x128x32 with 8 waves (2x4, 64x32 per wave, one block per CU) and 64x64x32 with 4 waves (2x2, 32x32 per wave,
+// four blocks per CU).  LDS rows are padded to 36 dwords (16 consecutive rows hit 16 distinct 16-B slots of the 64-bank
+// row: conflict-free ds_read_b128), two LDS buffers.  The main loop is software-pipelined with ONE barrier per 32-deep
+// chunk: MFMAs of chunk k issue from one register fragment set while the wave reads chunk k+1's fragments from LDS into
+// the other, writes chunk k+2 to LDS and issues the global loads (16 B per lane, 128-B row segments) of chunk k+3.
 // The epilogue (bias, exact-erf GELU, residual add) runs on the accumulators; stores are 128-B row segments.
+// Measured (tools/kernel_micro.py, MUMPY_GEMM_DBG ablation): the bare MFMA loop sustains ~124 TFLOP/s on MI355X (79 % of
+// the 157 TFLOP/s datasheet fp32-matrix peak); the full kernel reaches 90-105 on well-shaped problems.
+#include <stdlib.h>
 #include "common.h"
 using namespace mumpy;
 
@@ -18,16 +22,20 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDR = 36;  // LDS row stride in dwords
 
+// waves per SIMD the register allocator must leave room for: 8 waves (one block) per CU for the 128x128 tile,
+// 16 waves (four blocks) per CU for the 64x64 tile
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2 : 4) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, const float* residual,
                                                      float* Y, int64_t M, int N, int K, int act, unsigned gn,
-                                                     int ksplit, float* slab, int64_t rpb, int64_t bstride) {
+                                                     int ksplit, float* slab, int64_t rpb, int64_t bstride, int dbg) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
-    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
-    constexpr int A_LD = BM * 8 / 256;  // float4 loads per thread per chunk
-    constexpr int B_LD = BN * 8 / 256;
+    constexpr int NT = 64 * (BM / WM) * (BN / WN);   // threads per block (4 or 8 waves)
+    constexpr int RPI = NT / 8;                      // tile rows staged per pass (8 lanes x 16 B per 32-float row)
+    constexpr int A_LD = BM / RPI;                   // float4 loads per thread per chunk
+    constexpr int B_LD = BN / RPI;
+    static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must divide over the staging passes");
     __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDR];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -49,47 +57,37 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 
     // A rows may be strided in blocks (rows m of block m / rpb start at X + (m / rpb) * bstride): lets a caller feed
     // (B, t, n, C) tokens of one time slice as an (B*n, C) operand without a copy.  Dense: rpb = M.
+    // Rows past M (and W rows past N) are CLAMPED to the last valid row instead of predicated: their products land in
+    // accumulator rows/columns the epilogue never stores, and the staging loads stay branch-free.
     const float* arow[A_LD];
+    const float* brow[B_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int64_t m = m0 + ld_row + 32 * i;
-        arow[i] = (m < M) ? X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4 : nullptr;
+        int64_t m = m0 + ld_row + RPI * i;
+        if (m > M - 1) m = M - 1;
+        arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
     }
-    auto load_global = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            areg[i] = arow[i] ? *reinterpret_cast<const f32x4*>(arow[i] + k0) : f32x4{0, 0, 0, 0};
+    for (int i = 0; i < B_LD; ++i) {
+        int n = n0 + ld_row + RPI * i;
+        if (n > N - 1) n = N - 1;
+        brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
+    }
+    auto gload = [&](int k0) {                                   // global -> staging registers (16 B per lane)
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i) {
-            const int n = n0 + ld_row + 32 * i;
-            breg[i] = (n < N) ? *reinterpret_cast<const f32x4*>(Wt + (int64_t)n * K + k0 + 4 * ld_c4) : f32x4{0, 0, 0, 0};
-        }
+        for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
     };
-    auto store_lds = [&](int buf) {
+    auto lstore = [&](int buf) {                                 // staging registers -> LDS tile
 #pragma unroll
         for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<f32x4*>(&lds[buf][(ld_row + 32 * i) * LDR + 4 * ld_c4]) = areg[i];
+            *reinterpret_cast<f32x4*>(&lds[buf][(ld_row + RPI * i) * LDR + 4 * ld_c4]) = areg[i];
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<f32x4*>(&lds[buf][(BM + ld_row + 32 * i) * LDR + 4 * ld_c4]) = breg[i];
+            *reinterpret_cast<f32x4*>(&lds[buf][(BM + ld_row + RPI * i) * LDR + 4 * ld_c4]) = breg[i];
     };
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int nk = K / ksplit / BK;
-    load_global(kbeg);
-    store_lds(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) load_global(kbeg + (kc + 1) * BK);
-        f32x4 af[TM][4], bf[TN][4];
+    auto fread = [&](int buf, f32x4 (&af)[TM][4], f32x4 (&bf)[TN][4]) {   // LDS -> MFMA operand fragments
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -100,6 +98,16 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 bf[j][q] = *reinterpret_cast<const f32x4*>(&lds[buf][(BM + wn * WN + 32 * j + c) * LDR + 16 * h + 4 * q]);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto mma = [&](const f32x4 (&af)[TM][4], const f32x4 (&bf)[TN][4]) {
 #pragma unroll
         for (int s = 0; s < 16; ++s)
 #pragma unroll
@@ -107,9 +115,37 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ X
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s >> 2][s & 3], bf[j][s >> 2][s & 3], acc[i][j], 0, 0, 0);
-        if (kc + 1 < nk) store_lds(buf ^ 1);
-        __syncthreads();
+    };
+
+    // Software pipeline, one barrier per chunk.  While the MFMAs of chunk k issue from fragment set A (B), the wave
+    //   - reads chunk k+1's fragments from LDS into set B (A),
+    //   - writes chunk k+2 (global-loaded one step ago) into the LDS buffer chunk k vacated,
+    //   - issues the global loads of chunk k+3,
+    // so LDS latency, the staging writes and the HBM/L2 latency all sit under MFMA issue.
+    const int nk = K / ksplit / BK;
+    f32x4 afA[TM][4], bfA[TN][4], afB[TM][4], bfB[TN][4];
+    gload(kbeg);
+    lstore(0);
+    if (nk > 1) gload(kbeg + BK);
+    __syncthreads();
+    fread(0, afA, bfA);
+    if (nk > 1) lstore(1);
+    if (nk > 2) gload(kbeg + 2 * BK);
+    __syncthreads();
+    for (int kc = 0; kc < nk; kc += 2) {
+        if (kc + 1 < nk && !(dbg & 4)) fread(1, afB, bfB);
+        mma(afA, bfA);
+        if (kc + 2 < nk && !(dbg & 2)) lstore(0);
+        if (kc + 3 < nk && !(dbg & 1)) gload(kbeg + (kc + 3) * BK);
+        if (!(dbg & 8)) __syncthreads();
+        if (kc + 1 >= nk) break;
+        if (kc + 2 < nk && !(dbg & 4)) fread(0, afA, bfA);
+        mma(afB, bfB);
+        if (kc + 3 < nk && !(dbg & 2)) lstore(1);
+        if (kc + 4 < nk && !(dbg & 1)) gload(kbeg + (kc + 4) * BK);
+        if (!(dbg & 8)) __syncthreads();
     }
+    if (dbg & 16) { if (acc[0][0][0] == 12345.678f) Y[0] = 1.f; return; }
 
     // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h
     if (ksplit > 1) {       // raw partial sums -> slab[ks][M][N]; bias/act/residual happen in splitk_reduce_kernel
@@ -166,33 +202,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 }
 
 struct Plan {
-    int tile;    // 0: 128x128, 1: 128x96, 2: 64x64
+    int tile;    // 0: 128x128 (8 waves), 2: 64x64 (4 waves)
     int ksplit;
     unsigned gn;
     int64_t gm;
 };
 
-// Shape heuristic (measured on MI355X, tools/gemm_shapes.py): 128-wide tiles need >= ~1.5 blocks per CU to pay;
-// below that the 64x64 tile quadruples the block count, and if the grid is still small and K is deep, K is split
-// so that every CU gets work (slices of >= 384).
+// Shape planner, fitted to tools/gemm_shapes.py timings on MI355X.  Blocks are dispatched dynamically, so a launch costs
+//   ceil(blocks / 256 CUs) x (time of one block at its residency).
+// 128x128 (one block per CU): unit time, but its prologue/epilogue are exposed (~2 chunk-times on top of K/32 chunks).
+// 64x64 (four co-resident per CU): 0.272 of the unit each (a quarter of the work at ~92 % efficiency: twice the staging
+// traffic per FLOP), never below 0.357 (a lone block cannot fill the CU); co-resident blocks hide each other's
+// prologue/epilogue.  When even the 64-tile grid leaves CUs idle and K is deep, K is split (slices >= 384).
+constexpr int NUM_CU = 256;
+
 Plan make_plan(int64_t M, int N, int K, bool allow_split) {
+    static const char* force = getenv("MUMPY_GEMM_FORCE");      // tuning hook: "tile,ksplit"
     Plan p;
-    const bool n96 = (N % 128 != 0 && N % 96 == 0);
-    const int64_t gm128 = (M + 127) / 128;
-    const unsigned gn128 = n96 ? N / 96 : (N + 127) / 128;
-    if (gm128 * gn128 >= 384) {
-        p.tile = n96 ? 1 : 0; p.ksplit = 1; p.gn = gn128; p.gm = gm128;
-        return p;
+    const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
+    const unsigned gn128 = (N + 127) / 128, gn64 = (N + 63) / 64;
+    const int64_t b128 = gm128 * gn128, b64 = gm64 * gn64;
+    const double nk = (double)K / BK;
+    const double t128 = (double)((b128 + NUM_CU - 1) / NUM_CU) * (nk + 2.0) / nk;
+    double t64 = (double)((b64 + NUM_CU - 1) / NUM_CU) * 0.272;
+    if (t64 < 0.357) t64 = 0.357;
+    t64 *= (nk + 0.5) / nk;
+    int tile = (t128 <= t64) ? 0 : 2;
+    int ks = 1;
+    if (tile == 2 && allow_split && b64 < 2 * NUM_CU && K >= 768) {
+        ks = (int)((3 * NUM_CU + b64 - 1) / b64);
+        if (ks > K / 384) ks = K / 384;
+        if (ks > 16) ks = 16;
+        while (ks > 1 && (K % (32 * ks)) != 0) --ks;
+        if (ks < 1) ks = 1;
     }
-    p.tile = 2; p.gm = (M + 63) / 64; p.gn = (N + 63) / 64; p.ksplit = 1;
-    const int64_t blocks = p.gm * p.gn;
-    if (allow_split && blocks < 512 && K >= 768) {
-        int s = (int)((768 + blocks - 1) / blocks);
-        if (s > K / 384) s = K / 384;
-        if (s > 16) s = 16;
-        while (s > 1 && (K % (32 * s)) != 0) --s;
-        p.ksplit = s < 1 ? 1 : s;
+    if (force) {
+        int ft = -1, fk = -1;
+        if (sscanf(force, "%d,%d", &ft, &fk) >= 1 && (ft == 0 || ft == 2)) {
+            tile = ft;
+            if (fk >= 1 && allow_split && K % (32 * fk) == 0) ks = fk; else if (fk >= 1) ks = 1;
+        }
     }
+    p.tile = tile; p.ksplit = ks;
+    p.gm = (tile == 2) ? gm64 : gm128;
+    p.gn = (tile == 2) ? gn64 : gn128;
     return p;
 }
 
@@ -203,11 +256,11 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
-#define MUMPY_GEMM(BM_, BN_, WM_, WN_)                                                                               \
-    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, bias, residual, \
-                       y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride)
-    if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 64);
-    else if (p.tile == 1) MUMPY_GEMM(128, 96, 32, 96);
+#define MUMPY_GEMM(BM_, BN_, WM_, WN_)                                                                             \
+    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)grid), dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, \
+                       s, x, W, bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, dbgmask)
+    static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
+    if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32);
     else MUMPY_GEMM(64, 64, 32, 32);
 #undef MUMPY_GEMM
     MUMPY_CHECK_LAUNCH("linear");
