@@ -33,7 +33,7 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd"}
+HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd", "mumpy_gn_stats_nhwc_fwd", "mumpy_gn_apply_resample_nhwc_fwd"}
 GFLOP_PER_CLIP_T5 = 253.9         # whole-forward algorithmic work at T=5
 
 
@@ -90,6 +90,48 @@ def profile_kernels(enc, dec, x):
         rows.append(row)
     rows.sort(key=lambda r: -r["ms"])
     return rows, total_ms
+
+
+def north_star_kernels(batch, frames, dev):
+    """The two kernels BASELINE.json names, timed on their LARGEST launch of this workload (stage 0: view 3's shifted
+    window attention; view 2 <- view 3 deformable sampling) with events on the launch stream, 20 launches each."""
+    from models.modules.swinTransformer import build_shift_mask, relative_position_index
+    from mumpy_hip import ops
+    out = {}
+    hs, w, c = frames * 56, 56, 128
+    qkv = torch.randn(batch, hs * w, 3 * c, device=dev)
+    bias = ops.expand_relpos_bias(torch.randn(169, c // 32, device=dev) * 0.2, relative_position_index(7, 7).to(dev))
+    tab, ids = ops.compact_attn_mask(build_shift_mask(hs, w, 7, 3).to(dev))
+
+    def timed(fn, reps=20):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    t = timed(lambda: ops.window_attention(qkv, bias, batch, hs, w, c, 3, 32 ** -0.5, tab, ids))
+    units = batch * (hs // 7) * (w // 7) * (c // 32)
+    ach = units * 307328.0 / t / 1e12
+    out["window_attention"] = {"kernel": "win_attn_self_kernel", "launch": f"B={batch}, grid {hs}x{w}, C={c}, shift 3: {units} (window,head) units",
+                               "bound": "mfma", "flop_per_unit": 307328, "avg_us": round(t * 1e6, 2), "achieved": round(ach, 2),
+                               "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                               "hbm_bytes_per_unit": 25088, "hbm_gbs": round(units * 25088 / t / 1e9, 1)}
+    c2 = 96
+    nwin = batch * (hs // 7) * (w // 7)
+    x2 = torch.randn(batch, hs * w, c2, device=dev)
+    pos = torch.rand(batch * 64, 3, 49, 2, device=dev) * 2 - 1
+    t = timed(lambda: ops.deform_sample(x2, pos, batch, hs, w, c2, batch * 64))
+    nbytes = 4.0 * (2 * nwin * 49 * c2 + nwin * 3 * 49 * 2)
+    ach = nbytes / t / 1e9
+    out["deform_sample"] = {"kernel": "deform_sample_kernel<96>", "launch": f"{nwin} kv windows x 49 points x {c2} ch",
+                            "bound": "hbm", "bytes_per_launch": int(nbytes), "avg_us": round(t * 1e6, 2), "achieved": round(ach, 1),
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4)}
+    return out
 
 
 def cpu_baseline(frames, sample_b):
@@ -218,6 +260,7 @@ def main():
                        "global_batch": args.batch * world, "launch": "eager" if fwd is None else "hipGraph replay",
                        "parallelism": f"batch-sharded x{world}, one metric all-reduce"},
             "roofline": dom,
+            "north_star_kernels": north_star_kernels(args.batch, args.frames, dev),
             "kernels": kernels,
             "forward_gflop_per_clip": GFLOP_PER_CLIP_T5 if args.frames == 5 else None,
             "whole_forward_frac_of_f32_mfma_peak": round(GFLOP_PER_CLIP_T5 * 1e9 * clips / dt / world / (PEAK_F32_MFMA_TFLOPS * 1e12), 4)

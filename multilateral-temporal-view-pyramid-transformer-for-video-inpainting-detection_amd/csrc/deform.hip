@@ -101,21 +101,26 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// sampling: one thread per (kv window, point, 4 channels).  Lanes run over channels, so each of the four corner
-// reads is a contiguous row segment; the 49xC window tile (<= 150 KB) is served by L1/L2 after its first touch, so
-// HBM sees x2 once and the sampled map once.
+// sampling: one block per kv window, a thread per (point, 4 channels); lanes run over channels, so each of the four
+// corner reads is a contiguous row segment.  The 49xC window tile (<= 150 KB) is served by L1/L2 after its first touch:
+// HBM sees x2 once and the sampled map once.  Window decode is scalar (per block) and the channel count is a template
+// constant, so the per-thread index math is two constant divisions (the first version spent its time in 64-bit
+// runtime divisions: 3.6 TB/s).
+template <int C>
 __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restrict__ x2, const float* __restrict__ pos,
-                                                            float* __restrict__ out, int Hs2, int W, int C, int Cg,
-                                                            int nWx, int nW2, int nq, int64_t total) {
-    const int c4n = C >> 2;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int c4 = (int)(idx % c4n);
-        const int64_t t = idx / c4n;
-        const int p = (int)(t % WT);
-        const int64_t b2 = t / WT;
-        const int g = (4 * c4) / Cg;
-        const float* ps = pos + ((((int64_t)(b2 % nq)) * 3 + g) * WT + p) * 2;
-        const float gy = ps[0], gx = ps[1];
+                                                            float* __restrict__ out, int Hs2, int W, int nWx, int nW2,
+                                                            int nq) {
+    constexpr int C4N = C / 4, CG = C / 3;
+    const int b2 = blockIdx.x;
+    const int b = b2 / nW2, n = b2 - b * nW2;
+    const int wy = n / nWx, wx = n - wy * nWx;
+    const float* base = x2 + ((int64_t)b * Hs2 * W + (int64_t)wy * WS * W + wx * WS) * C;   // window's top-left token
+    const float* pw = pos + (int64_t)(b2 % nq) * 3 * WT * 2;
+    float* ob = out + (int64_t)b2 * WT * C;
+    for (int idx = threadIdx.x; idx < WT * C4N; idx += 256) {
+        const int p = idx / C4N, c4 = idx - p * C4N;
+        const int g = (4 * c4) / CG;
+        const float gy = pw[(g * WT + p) * 2], gx = pw[(g * WT + p) * 2 + 1];
         // grid_sample, align_corners=True: pixel = (g + 1) / 2 * (size - 1)
         const float iy = ((gy + 1.0f) * 0.5f) * 6.0f;
         const float ix = ((gx + 1.0f) * 0.5f) * 6.0f;
@@ -125,20 +130,16 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restr
         const float wne = (ix - x0f) * (y0f + 1.0f - iy);
         const float wsw = (x0f + 1.0f - ix) * (iy - y0f);
         const float wse = (ix - x0f) * (iy - y0f);
-        const int64_t b = b2 / nW2;
-        const int n = (int)(b2 - b * nW2);
-        const int wy = n / nWx, wx = n - wy * nWx;
-        const float* base = x2 + ((int64_t)b * Hs2 * W) * C + 4 * c4;
+        const float* src = base + 4 * c4;
         auto corner = [&](int yy, int xx) -> f32x4 {
             if (yy < 0 || yy >= WS || xx < 0 || xx >= WS) return f32x4{0, 0, 0, 0};   // zeros padding
-            const int tok = (wy * WS + yy) * W + wx * WS + xx;
-            return *reinterpret_cast<const f32x4*>(base + (int64_t)tok * C);
+            return *reinterpret_cast<const f32x4*>(src + (yy * W + xx) * C);
         };
         f32x4 r = corner(y0, x0) * wnw;
         r += corner(y0, x0 + 1) * wne;
         r += corner(y0 + 1, x0) * wsw;
         r += corner(y0 + 1, x0 + 1) * wse;
-        *reinterpret_cast<f32x4*>(out + (b2 * WT + p) * C + 4 * c4) = r;
+        *reinterpret_cast<f32x4*>(ob + idx * 4) = r;
     }
 }
 
@@ -211,13 +212,21 @@ extern "C" int mumpy_deform_sample_fwd(const float* x2, const float* pos, float*
     MUMPY_REQUIRE(aligned16(x2) && aligned16(out), MUMPY_EALIGN, "deform_sample: pointers must be 16-byte aligned");
     MUMPY_REQUIRE(B > 0 && Hs2 > 0 && W > 0 && Hs2 % WS == 0 && W % WS == 0 && nq > 0, MUMPY_EINVAL,
                   "deform_sample: bad grid (%d,%d) / nq=%d", Hs2, W, nq);
-    MUMPY_REQUIRE(C % 12 == 0, MUMPY_EINVAL, "deform_sample: C=%d must be a multiple of 12", C);
+    MUMPY_REQUIRE(C == 96 || C == 192 || C == 384 || C == 768, MUMPY_EINVAL,
+                  "deform_sample: C=%d is not one of the encoder widths 96/192/384/768", C);
     const int nWx = W / WS, nW2 = (Hs2 / WS) * nWx;
-    const int64_t total = (int64_t)B * nW2 * WT * (C / 4);
-    int64_t grid = (total + 255) / 256;
-    if (grid > 256 * 16) grid = 256 * 16;
-    hipLaunchKernelGGL(deform_sample_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x2, pos, out, Hs2, W,
-                       C, C / 3, nWx, nW2, nq, total);
+    const int64_t nwin = (int64_t)B * nW2;
+    MUMPY_REQUIRE(nwin < (1ll << 31), MUMPY_ERANGE, "deform_sample: too many windows");
+#define MUMPY_SAMPLE(C_)                                                                                             \
+    hipLaunchKernelGGL(deform_sample_kernel<C_>, dim3((unsigned)nwin), dim3(256), 0, as_stream(stream), x2, pos, out, Hs2, \
+                       W, nWx, nW2, nq)
+    switch (C) {
+        case 96: MUMPY_SAMPLE(96); break;
+        case 192: MUMPY_SAMPLE(192); break;
+        case 384: MUMPY_SAMPLE(384); break;
+        default: MUMPY_SAMPLE(768); break;
+    }
+#undef MUMPY_SAMPLE
     MUMPY_CHECK_LAUNCH("deform_sample");
     return 0;
 }

@@ -14,7 +14,13 @@
 //     accumulator->operand trick: k-slot h of step (jt,g,e) is key 32jt+8g+4h+e, which is exactly the key the
 //     lane's register 4g+e holds); V rows are loaded in that same key order, one dword per lane (128-B rows).
 //   * keys >= 49 are masked by the -1e30 columns of the pre-padded bias; queries >= 49 are never stored.
-// The unit is HBM-bound (12.25 FLOP/B): no LDS staging, ~25 KB in flight per wave, >= 8 waves per CU.
+// The unit is HBM-bound (12.25 FLOP/B): no LDS staging, ~25 KB in flight per wave, 12 waves per CU (146 VGPRs).
+// Measured on the largest launch of the B=8,T=5 forward (10,240 units, MUMPY_WA_DBG ablation, MI355X): loads only 35 us
+// (5.6 TB/s), MFMAs only 33 us, stores 10 us, launch + bias staging 10 us; the full kernel takes 72-83 us: the three
+// rounds of resident waves run in lockstep, so the phases add instead of overlapping.  A register-prefetching persistent
+// variant (next window's Q/K/V loaded under the current MFMAs) was built and measured SLOWER (85-100 us: 256 VGPRs +
+// spills, 2 waves/SIMD, per-wave VMEM queue depth); the next step is an LDS-DMA (global_load_lds) ring for K/V.
+#include <stdlib.h>
 #include "common.h"
 using namespace mumpy;
 
@@ -27,6 +33,7 @@ struct SelfArgs {
     const float* mask_tab;  // (nU,64,64) or null
     const int32_t* mask_id; // (n_mask) or null; window bw uses mask_id[bw % n_mask]
     int B, Hs, W, C, nH, shift, nWx, nW, n_mask;
+    int dbg;               // diagnostic ablation mask (MUMPY_WA_DBG): 1 skip q/k/v loads, 2 skip MFMAs+softmax, 4 skip stores
     float scale;
     int64_t units;
 };
@@ -51,61 +58,56 @@ __device__ __forceinline__ void load_frag(f32x4 (&f)[4], const float* row, bool 
     for (int i = 0; i < 4; ++i) f[i] = valid ? *reinterpret_cast<const f32x4*>(row + 4 * i) : f32x4{0, 0, 0, 0};
 }
 
-// S^T += K Q^T for the 2x2 tiles; q already scaled
-__device__ __forceinline__ void qk_product(f32x16 (&s)[2][2], const f32x4 (&kf)[2][4], const f32x4 (&qf)[2][4]) {
+// S^T[jt] += K[jt] Q^T for ONE query tile (32 queries on the lanes); q already scaled
+__device__ __forceinline__ void qk_product(f32x16 (&s)[2], const f32x4 (&kf)[2][4], const f32x4 (&qf)[4]) {
 #pragma unroll
     for (int st = 0; st < 16; ++st) {
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int it = 0; it < 2; ++it) s[jt][it] = mfma32(kf[jt][st >> 2][st & 3], qf[it][st >> 2][st & 3], s[jt][it]);
+        for (int jt = 0; jt < 2; ++jt) s[jt] = mfma32(kf[jt][st >> 2][st & 3], qf[st >> 2][st & 3], s[jt]);
     }
 }
 
-// add bias (+mask) rows and run the softmax over keys for the two query columns this lane owns
-__device__ __forceinline__ void bias_softmax(f32x16 (&s)[2][2], const float* bias_h, const float* mask_w, int c, int h,
-                                             float post_scale) {
+// add bias (+mask) rows and run the softmax over keys for the query column this lane owns (query i = 32*it + c)
+template <typename BIAS>
+__device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const float* mask_w, int i, int h,
+                                             float post_scale, bool skip = false) {
     constexpr float NEG = -1e30f;
+    if (skip) return;
+    float m = NEG;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        const int i = 32 * it + c;
-        float m = NEG;
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int g = 0; g < 4; ++g) {
+            if (jt == 1 && g == 3) {  // keys 56..63: all padding
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                if (jt == 1 && g == 3) {  // keys 56..63: all padding
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s[jt][it][4 * g + e] = NEG;
-                    continue;
-                }
-                const int off = i * 64 + 32 * jt + 8 * g + 4 * h;
-                f32x4 b = *reinterpret_cast<const f32x4*>(bias_h + off);
-                if (mask_w) b += *reinterpret_cast<const f32x4*>(mask_w + off);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float v = s[jt][it][4 * g + e] * post_scale + b[e];
-                    s[jt][it][4 * g + e] = v;
-                    m = fmaxf(m, v);
-                }
+                for (int e = 0; e < 4; ++e) s[jt][4 * g + e] = NEG;
+                continue;
             }
-        m = fmaxf(m, __shfl_xor(m, 32));
-        float sum = 0.f;
+            f32x4 b = bias_at(jt, g);                                  // keys 32jt+8g+4h .. +3 of query i
+            if (mask_w) b += *reinterpret_cast<const f32x4*>(mask_w + i * 64 + 32 * jt + 8 * g + 4 * h);
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(s[jt][it][r] - m);
-                s[jt][it][r] = e;
-                sum += e;
+            for (int e = 0; e < 4; ++e) {
+                const float v = s[jt][4 * g + e] * post_scale + b[e];
+                s[jt][4 * g + e] = v;
+                m = fmaxf(m, v);
             }
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
+        }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+    for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][it][r] *= inv;
-    }
+        for (int r = 0; r < 16; ++r) {
+            const float e = __expf(s[jt][r] - m);
+            s[jt][r] = e;
+            sum += e;
+        }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[jt][r] *= inv;
 }
 
 // the 25 (jt,g,e) MFMA steps of P V that can hold a key < 49; key of lane half h is 32jt+8g+4h+e
@@ -130,35 +132,36 @@ __device__ __forceinline__ void load_v(float (&vf)[2][16], VROW vrow, int c, int
     });
 }
 
-__device__ __forceinline__ void pv_product(f32x16 (&o)[2], const f32x16 (&s)[2][2], const float (&vf)[2][16]) {
-    for_pv_steps([&](int jt, int g, int e) {
-        o[0] = mfma32(s[jt][0][4 * g + e], vf[jt][4 * g + e], o[0]);
-        o[1] = mfma32(s[jt][1][4 * g + e], vf[jt][4 * g + e], o[1]);
-    });
+__device__ __forceinline__ void pv_product(f32x16& o, const f32x16 (&s)[2], const float (&vf)[2][16]) {
+    for_pv_steps([&](int jt, int g, int e) { o = mfma32(s[jt][4 * g + e], vf[jt][4 * g + e], o); });
 }
 
 template <typename OROW>
-__device__ __forceinline__ void store_o(const f32x16 (&o)[2], OROW orow, int c, int h) {
+__device__ __forceinline__ void store_o(const f32x16& o, int it, OROW orow, int c, int h) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
-            if (i < WT) orow(i)[c] = o[it][r];
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
+        if (i < WT) orow(i)[c] = o[r];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void win_attn_self_kernel(SelfArgs a) {
+constexpr int BLD = 68;   // LDS row stride of the staged bias table: 68 floats -> conflict-free ds_read_b128 across rows
+
+__global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     __shared__ int tok_tab[4][64];
+    __shared__ __attribute__((aligned(16))) float bias_s[WT * BLD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
-    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
-    if (u >= a.units) return;
-    const int head = (int)(u % a.nH);
-    const int64_t bw = u / a.nH;                 // window index over the batch
-    const int n = (int)(bw % a.nW);
+    // a block = ONE head x 4 consecutive windows: the head's 49x49 bias table is staged once in LDS (the per-lane
+    // row-strided reads of it would otherwise cost as many L1 tag cycles as the MFMAs); a (window, head) unit owns its
+    // 128-B q/k/v row segments exclusively, so grouping by head costs no extra HBM or L2 traffic.
+    const int head = blockIdx.x % a.nH;
+    int64_t bw = (int64_t)(blockIdx.x / a.nH) * 4 + wave;                // window index over the batch
+    const bool active = bw < (int64_t)a.B * a.nW;
+    if (!active) bw = 0;                                                 // idle wave of a ragged last block: loads
+    const int n = (int)(bw % a.nW);                                      // window 0 (valid memory), stores nothing
     const int64_t b = bw / a.nW;
     const int wy = n / a.nWx, wx = n - wy * a.nWx;
     int* tt = tok_tab[wave];
@@ -168,51 +171,71 @@ __global__ __launch_bounds__(256) void win_attn_self_kernel(SelfArgs a) {
     const float* base = a.qkv + b * L * 3 * a.C + head * HD;
     const int rs = 3 * a.C;
 
+    // q/k/v go straight to registers and are in flight while the bias table is staged
     f32x4 qf[2][4], kf[2][4];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int p = 32 * t + c;
         const bool valid = p < WT;
         const float* row = base + (int64_t)tt[p & 63] * rs + 16 * h;
-        load_frag(qf[t], row, valid);
-        load_frag(kf[t], row + a.C, valid);
+        load_frag(qf[t], row, valid && !(a.dbg & 1));
+        load_frag(kf[t], row + a.C, valid && !(a.dbg & 1));
     }
     float vf[2][16];
     const float* vbase = base + 2 * a.C;
-    load_v(vf, [&](int j) { return vbase + (int64_t)tt[j] * rs; }, c, h);
+    if (!(a.dbg & 1)) load_v(vf, [&](int j) { return vbase + (int64_t)tt[j] * rs; }, c, h);
+    else for_pv_steps([&](int jt, int g, int e) { vf[jt][4 * g + e] = 1.f; });
+    {
+        const float* bsrc = a.bias + (int64_t)head * 4096;
+        for (int idx = threadIdx.x; idx < WT * 16; idx += 256) {
+            const int row = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(&bias_s[row * BLD + 4 * c4]) = *reinterpret_cast<const f32x4*>(bsrc + row * 64 + 4 * c4);
+        }
+    }
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) qf[t][i] *= a.scale;   // q = q * scale before QK^T (swin:145)
-
-    f32x16 s[2][2];
-#pragma unroll
-    for (int jt = 0; jt < 2; ++jt)
-#pragma unroll
-        for (int it = 0; it < 2; ++it)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][it][r] = 0.f;
-    qk_product(s, kf, qf);
 
     const float* mask_w = nullptr;
     if (a.mask_id) {
         const int id = a.mask_id[(int)(bw % a.n_mask)];
         if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
     }
-    bias_softmax(s, a.bias + (int64_t)head * 4096, mask_w, c, h, 1.0f);
-
-    f32x16 o[2];
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[it][r] = 0.f;
-    pv_product(o, s, vf);
     float* obase = a.out + b * L * a.C + head * HD;
-    store_o(o, [&](int i) { return obase + (int64_t)tt[i] * a.C; }, c, h);
+    // the two 32-query tiles go one after the other: S needs 32 accumulator registers instead of 64
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        f32x16 s[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
+        if (!(a.dbg & 2)) qk_product(s, kf, qf[it]);
+        else { s[0][0] = kf[0][0][0] + qf[it][0][0]; s[1][3] = kf[1][1][1] * qf[it][2][1]; }
+        const int qi = 32 * it + c;
+        const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];        // padded queries re-read row 48
+        bias_softmax(s, [&](int jt, int g) {
+            f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
+            if (jt == 1 && g == 2) {                                               // keys 48..55: only key 48 is real
+                if (h) bv = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
+                else { bv.y = -1e30f; bv.z = -1e30f; bv.w = -1e30f; }
+            }
+            return bv;
+        }, mask_w, qi, h, 1.0f, (a.dbg & 2) != 0);
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        if (!(a.dbg & 2)) pv_product(o, s, vf);
+        else { o[0] = s[0][0] + vf[0][0]; o[5] = s[1][2] * vf[1][8]; }
+        if (active && !(a.dbg & 4)) store_o(o, it, [&](int i) { return obase + (int64_t)tt[i] * a.C; }, c, h);
+        else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1.f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void win_attn_cross_kernel(CrossArgs a) {
+__global__ __launch_bounds__(256, 2) void win_attn_cross_kernel(CrossArgs a) {
     __shared__ int tok_tab[4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -250,19 +273,28 @@ __global__ __launch_bounds__(256) void win_attn_cross_kernel(CrossArgs a) {
         const float* vbase = kbase + a.C;
         load_v(vf, [&](int j) { return vbase + (int64_t)j * 2 * a.C; }, c, h);
 
-        f32x16 s[2][2];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+        for (int it = 0; it < 2; ++it) {
+            f32x16 s[2];
 #pragma unroll
-            for (int it = 0; it < 2; ++it)
+            for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) s[jt][it][r] = 0.f;
-        qk_product(s, kf, qf);
-        bias_softmax(s, a.padmask, nullptr, c, h, a.scale);   // scale on the product (deform:364)
-        pv_product(o, s, vf);
+                for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
+            qk_product(s, kf, qf[it]);
+            bias_softmax(s, [&](int jt, int g) {                               // no bias: only the 49->64 key padding
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (jt == 1 && g == 2) {
+                    if (h) bv = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
+                    else { bv.y = -1e30f; bv.z = -1e30f; bv.w = -1e30f; }
+                }
+                return bv;
+            }, nullptr, 32 * it + c, h, a.scale);                               // scale on the product (deform:364)
+            pv_product(o[it], s, vf);
+        }
     }
     float* obase = a.out + b1 * WT * a.C + head * HD;
-    store_o(o, [&](int i) { return obase + (int64_t)i * a.C; }, c, h);
+    store_o(o[0], 0, [&](int i) { return obase + (int64_t)i * a.C; }, c, h);
+    store_o(o[1], 1, [&](int i) { return obase + (int64_t)i * a.C; }, c, h);
 }
 
 }  // namespace
@@ -284,8 +316,10 @@ extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const fl
     a.qkv = qkv; a.out = out; a.bias = bias; a.mask_tab = mask_tab; a.mask_id = mask_id;
     a.B = B; a.Hs = Hs; a.W = W; a.C = C; a.nH = C / HD; a.shift = shift;
     a.nWx = W / WS; a.nW = (Hs / WS) * (W / WS); a.scale = scale; a.n_mask = n_mask > 0 ? n_mask : 1;
+    static const int dbgmask = getenv("MUMPY_WA_DBG") ? atoi(getenv("MUMPY_WA_DBG")) : 0;
+    a.dbg = dbgmask;
     a.units = (int64_t)B * a.nW * a.nH;
-    const int64_t grid = (a.units + 3) / 4;
+    const int64_t grid = (((int64_t)B * a.nW + 3) / 4) * a.nH;      // (quads of windows) x heads
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "window_attention: too many windows");
     hipLaunchKernelGGL(win_attn_self_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention");
