@@ -42,14 +42,29 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     const int c = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     // 1-D grid, XCD-aware: blocks are dealt round-robin over the 8 XCDs, so remap the id such that each XCD owns a
-    // contiguous run of tiles, N fastest -> the gn tiles that share an x row-panel (and the W panels, which are
-    // small) are served by ONE L2 instead of eight (bijective form, cdna guide T1).
+    // contiguous run of the tile order (bijective form, cdna guide T1).  The tile order itself is (N-group, M, N-in-group)
+    // with NG tiles per group: the blocks resident on an XCD then share a few x row-panels and ONE narrow slice of W, which
+    // stay in the 4 MiB L2.  (PMC before this ordering, M=7840 N=2048 K=512: 240 MB fetched for 20 MB of operands --
+    // W was re-read from the Infinity Cache for every row panel; profiles/r01_pmc_traffic.md.)
+    constexpr unsigned NG = (BM >= 128) ? 4 : 8;
     const unsigned nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int ks = (int)(wgid % (unsigned)ksplit);       // K slice (split-K): slices of one tile run side by side
     wgid /= (unsigned)ksplit;
-    const int64_t m0 = (int64_t)(wgid / gn) * BM;
-    const int n0 = (int)(wgid % gn) * BN;
+    const unsigned gm = (unsigned)((M + BM - 1) / BM);
+    const unsigned full = (gn / NG) * NG;                // tiles in complete N-groups
+    unsigned tm, tn;
+    if (wgid < gm * full) {
+        const unsigned grp = wgid / (gm * NG), rem = wgid - grp * gm * NG;
+        tm = rem / NG;
+        tn = grp * NG + rem % NG;
+    } else {                                             // the last, narrower N-group
+        const unsigned wdt = gn - full, rem = wgid - gm * full;
+        tm = rem / wdt;
+        tn = full + rem % wdt;
+    }
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = (int)tn * BN;
     const int kbeg = ks * (K / ksplit);
 
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
