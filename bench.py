@@ -33,7 +33,8 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
-HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd", "mumpy_gn_stats_nhwc_fwd", "mumpy_gn_apply_resample_nhwc_fwd"}
+HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd", "mumpy_gn_stats_nhwc_fwd", "mumpy_gn_apply_resample_nhwc_fwd", "mumpy_final_conv_fwd", "mumpy_patch_merge_ln_fwd",
+             "mumpy_add_fwd"}
 GFLOP_PER_CLIP_T5 = 253.9         # whole-forward algorithmic work at T=5
 
 

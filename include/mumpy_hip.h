@@ -67,6 +67,16 @@ int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_
                           const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- Convolution, NHWC, stride 1, zero "same" padding, odd kernel: y = act(conv(x, w) + bias) + residual
+ *      — the decoder's 3x3 / 7x1 / 1x7 nn.Conv2d (decoder.py:9,24-31,68-95,149-178) as an implicit GEMM on the
+ *      mumpy_linear_fwd tile machinery (K index = (tap, channel); borders predicated, nothing is unfolded).
+ * x (B,H,W,Cin), w_krsc (Cout,kh,kw,Cin) = the channels_last image of the nn.Conv2d weight, y/residual (B,H,W,Cout).
+ * Cin % 32 == 0, Cout % 32 == 0.  Workspace as for mumpy_linear_ws_fwd (mumpy_conv2d_workspace_bytes). */
+int64_t mumpy_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw);
+int mumpy_conv2d_nhwc_fwd(const float* x, const float* w_krsc, const float* bias, const float* residual, float* y,
+                          int B, int H, int W, int Cin, int Cout, int kh, int kw, int act, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* ---- Swin window attention core  — swin:54-83 (partition/reverse), 273,295 (roll), 145-163 (softmax(QK^T)V)
  * qkv:  (B, Hs*W, 3*C) raster token order over the stacked grid Hs = t*H rows by W columns; channel
  *       layout [q|k|v][head][32] exactly as nn.Linear(C,3C) emits it (swin:142).
@@ -158,6 +168,11 @@ int mumpy_gn_apply_resample_nhwc_fwd(const float* x, const float* partial, int n
                                      int align_corners, int ep_mode, const float* ep_a, const float* ep_b,
                                      float* out, int out_ctot, int out_coff, int B, int H, int W, int C,
                                      void* stream);
+
+/* final_out (decoder.py:95,223): Conv2d(32 -> 1, 3x3, pad 1) on x (B,H,W,32) NHWC, w_krsc (1,3,3,32), bias (1);
+ * logits (B,1,H,W) fp32; mask (B,1,H,W) uint8 = sigmoid(logit) > thr, or NULL (the eval tail of test.py:100-108 fused). */
+int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias, float* logits, uint8_t* mask, int B,
+                         int H, int W, float thr, void* stream);
 
 /* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
 int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);

@@ -22,13 +22,20 @@ namespace {
 constexpr int BK = 32;
 constexpr int LDR = 36;  // LDS row stride in dwords
 
+// Implicit-GEMM convolution (NHWC, stride 1, "same" zero padding): out pixel m = (b,y,x), K index = (tap, c) with
+// tap = dy*kw + dx -- exactly the GEMM below with the A row address shifted by a per-chunk tap offset and a border
+// predicate.  The weight is the channels_last (KRSC) image of the nn.Conv2d kernel == an (N, K) row-major matrix.
+struct ConvGeom {
+    int H, W, Cin, kh, kw, ph, pw;
+};
+
 // waves per SIMD the register allocator must leave room for: 8 waves (one block) per CU for the 128x128 tile,
 // 16 waves (four blocks) per CU for the 64x64 tile
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2 : 4) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2 : (CONV ? 3 : 4)) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, const float* residual,
                                                      float* Y, int64_t M, int N, int K, int act, unsigned gn,
-                                                     int ksplit, float* slab, int64_t rpb, int64_t bstride, int dbg) {
+                                                     int ksplit, float* slab, int64_t rpb, int64_t bstride, int dbg, ConvGeom cg) {
     constexpr int TM = WM / 32, TN = WN / 32;
     constexpr int WAVES_N = BN / WN;
     constexpr int NT = 64 * (BM / WM) * (BN / WN);   // threads per block (4 or 8 waves)
@@ -76,11 +83,20 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     // accumulator rows/columns the epilogue never stores, and the staging loads stay branch-free.
     const float* arow[A_LD];
     const float* brow[B_LD];
+    int ayx[A_LD];                                               // conv: (y << 16) | x of the staged output pixel
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         int64_t m = m0 + ld_row + RPI * i;
         if (m > M - 1) m = M - 1;
-        arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
+        if (CONV) {
+            const int x = (int)(m % cg.W);
+            const int y = (int)((m / cg.W) % cg.H);
+            ayx[i] = (y << 16) | x;
+            arow[i] = X + m * cg.Cin + 4 * ld_c4;
+        } else {
+            ayx[i] = 0;
+            arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
+        }
     }
 #pragma unroll
     for (int i = 0; i < B_LD; ++i) {
@@ -89,8 +105,21 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
         brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
     }
     auto gload = [&](int k0) {                                   // global -> staging registers (16 B per lane)
+        if (CONV) {
+            const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;     // wave-uniform: scalar ALU
+            const int dy = tap / cg.kw - cg.ph, dx = tap % cg.kw - cg.pw;
+            const int off = (dy * cg.W + dx) * cg.Cin + c0;
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+            for (int i = 0; i < A_LD; ++i) {
+                const int yy = (ayx[i] >> 16) + dy, xx = (ayx[i] & 0xffff) + dx;
+                const bool ok = (unsigned)yy < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(arow[i] + (ok ? off : 0));   // own pixel when outside
+                areg[i] = ok ? v : f32x4{0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+        }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
     };
@@ -265,18 +294,26 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split) {
 }
 
 int launch_linear(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
-                  int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0) {
+                  int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0,
+                  const ConvGeom* conv = nullptr) {
     if (rpb <= 0) { rpb = M; bstride = 0; }
+    const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
     Plan p = make_plan(M, N, K, ws != nullptr);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
-#define MUMPY_GEMM(BM_, BN_, WM_, WN_)                                                                             \
-    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_>), dim3((unsigned)grid), dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, \
-                       s, x, W, bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, dbgmask)
+#define MUMPY_GEMM(BM_, BN_, WM_, WN_, CV_)                                                                        \
+    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_, CV_>), dim3((unsigned)grid),                               \
+                       dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, s, x, W, bias, residual, y, M, N, K, act, p.gn, p.ksplit, \
+                       ws, rpb, bstride, dbgmask, cg)
     static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
-    if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32);
-    else MUMPY_GEMM(64, 64, 32, 32);
+    if (conv) {
+        if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32, true);
+        else MUMPY_GEMM(64, 64, 32, 32, true);
+    } else {
+        if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32, false);
+        else MUMPY_GEMM(64, 64, 32, 32, false);
+    }
 #undef MUMPY_GEMM
     MUMPY_CHECK_LAUNCH("linear");
     if (p.ksplit > 1) {
@@ -336,4 +373,23 @@ extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int
                   (long long)M, (long long)rows_per_block);
     return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream), rows_per_block, block_stride);
+}
+
+extern "C" int64_t mumpy_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    return mumpy_linear_workspace_bytes((int64_t)B * H * W, Cout, kh * kw * Cin);
+}
+
+extern "C" int mumpy_conv2d_nhwc_fwd(const float* x, const float* w_krsc, const float* bias, const float* residual,
+                                     float* y, int B, int H, int W, int Cin, int Cout, int kh, int kw, int act,
+                                     void* workspace, int64_t workspace_bytes, void* stream) {
+    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0 && H < 32768 && W < 32768, MUMPY_EINVAL, "conv2d: bad image size %dx%d", H, W);
+    MUMPY_REQUIRE(kh > 0 && kw > 0 && (kh & 1) && (kw & 1), MUMPY_EINVAL, "conv2d: kernel %dx%d must be odd (same padding)", kh, kw);
+    MUMPY_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, MUMPY_EINVAL, "conv2d: Cin=%d and Cout=%d must be multiples of 32", Cin, Cout);
+    const int64_t M = (int64_t)B * H * W;
+    const int K = kh * kw * Cin;
+    if (int rc = check_linear_args(x, w_krsc, residual, y, M, Cout, K, act)) return rc;
+    MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "conv2d: workspace must be 16-byte aligned");
+    const ConvGeom cg{H, W, Cin, kh, kw, kh / 2, kw / 2};
+    return launch_linear(x, w_krsc, bias, residual, y, M, Cout, K, act, static_cast<float*>(workspace),
+                         workspace ? workspace_bytes : 0, as_stream(stream), 0, 0, &cg);
 }

@@ -11,8 +11,10 @@ Execution: the decoder is NHWC (torch.channels_last) end t
     bilinear x2/x4 (both align_corners modes), the "+ gcn*freq" / "* freq" / SEB multiply — is two hand-written
     kernels (mumpy_gn_stats_nhwc_fwd, mumpy_gn_apply_resample_nhwc_fwd).  decoder_5's (B,128,224,224) output and
     DAP's (B,32,448,448) intermediate are never formed.
-  * The spatial convolutions themselves (3x3, 7x1, 1x7; 8 % of the forward's FLOPs) still run on MIOpen via torch,
-    NHWC, on the same stream and inside the same hipGraph.  Returned tensors are logical NCHW with NHWC strides.
+  * The spatial convolutions (3x3, 7x1, 1x7; 8 % of the forward's FLOPs) are the hand-written implicit GEMM
+    mumpy_conv2d_nhwc_fwd (same MFMA tile machinery as the Linears; GCM's x_l + x_r rides in an epilogue), and
+    final_out (32 -> 1) is a fused streaming kernel that can also emit the thresholded mask.  No MIOpen / library
+    kernel is left on the path.  Returned tensors are logical NCHW with NHWC strides.
 """
 import torch
 import torch.nn as nn
@@ -113,13 +115,24 @@ class Decoder(nn.Module):
             d = self._derived[key] = Derived()
         return d.get(sources, fn)
 
-    def _conv(self, x, conv):
-        """MIOpen convolution, NHWC in / NHWC out; the channels_last weight copy is cached per weight version."""
-        w = self._cached(("w", id(conv)), (conv.weight,), lambda: conv.weight.contiguous(memory_format=torch.channels_last))
-        return F.conv2d(x, w, conv.bias, padding=conv.padding)
+    def _conv(self, x, conv, residual=None):
+        """nn.Conv2d (stride 1, same padding) as the hand-written implicit GEMM, NHWC in / NHWC out.  The (Cout,kh,kw,Cin)
+        weight image is cached per weight version; input channels are zero-padded to a multiple of 32 (only the 9-channel
+        frequency input needs it)."""
+        cin = conv.weight.shape[1]
+        pad = (-cin) % 32
+        w = self._cached(("w", id(conv)), (conv.weight,),
+                         lambda: F.pad(conv.weight.permute(0, 2, 3, 1), (0, pad)).contiguous())
+        if pad:
+            b, _, h, wd = x.shape
+            xp = torch.zeros(b, h, wd, cin + pad, device=x.device, dtype=torch.float32)
+            xp[..., :cin] = x.permute(0, 2, 3, 1)
+            x = xp.permute(0, 3, 1, 2)
+        return ops.conv2d_nhwc(x, w, conv.bias, residual=residual)
 
-    def _gcm(self, m, x):
-        return self._conv(self._conv(x, m.conv_l1), m.conv_l2) + self._conv(self._conv(x, m.conv_r1), m.conv_r2)
+    def _gcm(self, m, x):                                              # x_l + x_r fused into the last conv's epilogue
+        left = self._conv(self._conv(x, m.conv_l1), m.conv_l2)
+        return self._conv(self._conv(x, m.conv_r1), m.conv_r2, residual=left)
 
     @staticmethod
     def _gn(x, gn):
@@ -169,8 +182,8 @@ class Decoder(nn.Module):
         return ops.gn_apply_resample(x, g, act=ops.ACT_RELU, mean4=mean4, scale=2, align_corners=True, ep_mode=ep_mode,
                                      ep_a=ep_a, ep_b=ep_b)
 
-    def forward(self, x, view_x, ffinfo):
-        """x (B,2304,7,7), view_x[4][3] of (B,1,L,C), ffinfo (B,9,224,224) -> (logits (B,1,224,224), feats (B,32,224,224))."""
+    def _features(self, x, view_x, ffinfo):
+        """Everything up to DAP: -> x_feats (B,32,224,224), NHWC memory."""
         rgb1, rgb2, rgb3, rgb4 = [self._rgb_head(i, view_x[i], self.shape[i]) for i in range(4)]
         b, dev = x.shape[0], x.device
         freq0 = self._freq(self.decoder_frequency_0, ffinfo.contiguous(memory_format=torch.channels_last))
@@ -193,5 +206,19 @@ class Decoder(nn.Module):
         z = self._dec(self.decoder_2, gcn1 * freq3 + out1, ops.EP_ADD_MUL, gcn2, freq2)     # = decoder_3's input
         z = self._dec(self.decoder_3, z, ops.EP_ADD_MUL, gcn3, freq1)                       # = decoder_4's input
         z = self._dec(self.decoder_4, z, ops.EP_MUL, freq0)                                 # = decoder_5's input
-        x_feats = self._dec(self.decoder_5, z, mean4=True)                                  # DAP folded in
-        return self._conv(x_feats, self.final_out), x_feats
+        return self._dec(self.decoder_5, z, mean4=True)                                     # DAP folded in
+
+    def _final_weight(self):
+        return self._cached(("wf",), (self.final_out.weight,), lambda: self.final_out.weight.permute(0, 2, 3, 1).contiguous())
+
+    def forward(self, x, view_x, ffinfo):
+        """x (B,2304,7,7), view_x[4][3] of (B,1,L,C), ffinfo (B,9,224,224) -> (logits (B,1,224,224), feats (B,32,224,224))."""
+        x_feats = self._features(x, view_x, ffinfo)
+        return ops.final_conv(x_feats, self._final_weight(), self.final_out.bias), x_feats
+
+    def predict_mask(self, x, view_x, ffinfo, thr=0.5):
+        """forward() plus the eval tail of test.py:100-108 (sigmoid -> > thr -> uint8) emitted by the same last kernel:
+        -> (logits (B,1,224,224), mask uint8 (B,1,224,224), feats)."""
+        x_feats = self._features(x, view_x, ffinfo)
+        logits, mask = ops.final_conv(x_feats, self._final_weight(), self.final_out.bias, with_mask=True, thr=thr)
+        return logits, mask, x_feats

@@ -22,6 +22,9 @@ SIGNATURES = {
     "mumpy_gn_stats_nhwc_fwd": [c_f, c_f, c_i, c_l, c_i, c_i, c_i, c_f],
     "mumpy_gn_apply_resample_nhwc_fwd": [c_f, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i,
                                          c_i, c_i, c_i, c_i, c_f],
+    "mumpy_conv2d_nhwc_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f],
+    "mumpy_conv2d_workspace_bytes": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
+    "mumpy_final_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_window_attention_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_deform_offsets_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_sample_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

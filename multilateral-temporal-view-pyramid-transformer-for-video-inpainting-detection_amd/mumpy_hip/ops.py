@@ -108,6 +108,41 @@ def linear_rows(x_view, weight, bias=None, residual=None, out=None):
     return out
 
 
+def conv2d_nhwc(x, w_krsc, bias=None, act=ACT_NONE, residual=None):
+    """x logical (B,Cin,H,W) with NHWC memory; w_krsc (Cout,kh,kw,Cin) contiguous; stride 1, same padding.
+    Returns logical (B,Cout,H,W) with NHWC memory."""
+    x = _nhwc(x, "x")
+    b, cin, h, w = x.shape
+    w_krsc = _chk(w_krsc, "weight")
+    cout, kh, kw, cin2 = w_krsc.shape
+    if cin2 != cin:
+        raise RuntimeError(f"conv2d: input has {cin} channels, weight expects {cin2}")
+    out = empty_nhwc(b, cout, h, w, x.device)
+    if residual is not None:
+        residual = _nhwc(residual, "residual")
+    key = ("conv", b, h, w, cin, cout, kh, kw)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_conv2d_workspace_bytes(b, h, w, cin, cout, kh, kw))
+    ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None
+    _call("mumpy_conv2d_nhwc_fwd", _p(x), _p(w_krsc), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out),
+          b, h, w, cin, cout, kh, kw, act, _p(ws), wsb, _stream(), work=2.0 * b * h * w * cout * kh * kw * cin)
+    return out
+
+
+def final_conv(x, w_krsc, bias, with_mask=False, thr=0.5):
+    """x logical (B,32,H,W) NHWC -> logits (B,1,H,W) [, uint8 mask (B,1,H,W)]."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    if c != 32 or tuple(w_krsc.shape) != (1, 3, 3, 32):
+        raise RuntimeError("final_conv is built for Conv2d(32, 1, 3, padding=1)")
+    logits = torch.empty(b, 1, h, w, device=x.device, dtype=torch.float32)
+    mask = torch.empty(b, 1, h, w, device=x.device, dtype=torch.uint8) if with_mask else None
+    _call("mumpy_final_conv_fwd", _p(x), _p(_chk(w_krsc, "weight")), _p(_chk(bias, "bias")), _p(logits), _p(mask), b, h, w, thr,
+          _stream(), work=4.0 * (x.numel() + logits.numel()))
+    return (logits, mask) if with_mask else logits
+
+
 def _nhwc(t: torch.Tensor, name: str) -> torch.Tensor:
     """Logical (B,C,H,W) tensor whose memory is NHWC (torch.channels_last)."""
     if not t.is_cuda:
