@@ -17,9 +17,15 @@
 // The unit is HBM-bound (12.25 FLOP/B): no LDS staging, ~25 KB in flight per wave, 12 waves per CU (146 VGPRs).
 // Measured on the largest launch of the B=8,T=5 forward (10,240 units, MUMPY_WA_DBG ablation, MI355X): loads only 35 us
 // (5.6 TB/s), MFMAs only 33 us, stores 10 us, launch + bias staging 10 us; the full kernel takes 72-83 us: the three
-// rounds of resident waves run in lockstep, so the phases add instead of overlapping.  A register-prefetching persistent
-// variant (next window's Q/K/V loaded under the current MFMAs) was built and measured SLOWER (85-100 us: 256 VGPRs +
-// spills, 2 waves/SIMD, per-wave VMEM queue depth); the next step is an LDS-DMA (global_load_lds) ring for K/V.
+// rounds of resident waves run in lockstep, so the phases add instead of overlapping.  At one wave per SIMD the unit is
+// strictly serial: load 2-3.3 us + MFMA/softmax 4.7 us + store 0.7 us (87 us for 10 units per SIMD).
+// Tried and measured, not kept: (1) staggered block starts: no gain; (2) cross-unit REGISTER prefetch (next window's
+// q/k/v loaded under the current MFMAs), at 2 waves/SIMD (spills) and at 1 wave/SIMD with the whole 512-register file
+// (no spills): 81-100 us, no overlap -- hipcc's waitcnt insertion treats loop-carried loads conservatively (vmcnt is one
+// in-order counter: its waits for the CURRENT unit's registers drain the prefetch behind them; predicated loads and
+// a vector-loaded mask id made it worse).  What is kept from that work: persistent blocks (bias staged once), padded
+// token slots clamped to slot 48 (branch-free loads), scalar mask-id load.  Next step: an LDS-DMA (global_load_lds)
+// ring with hand-counted vmcnt, which takes the prefetch out of the compiler's bookkeeping.
 #include <stdlib.h>
 #include "common.h"
 using namespace mumpy;
@@ -32,7 +38,7 @@ struct SelfArgs {
     const float* bias;      // (nH,64,64)
     const float* mask_tab;  // (nU,64,64) or null
     const int32_t* mask_id; // (n_mask) or null; window bw uses mask_id[bw % n_mask]
-    int B, Hs, W, C, nH, shift, nWx, nW, n_mask;
+    int B, Hs, W, C, nH, shift, nWx, nW, n_mask, groups, stagger;
     int dbg;               // diagnostic ablation mask (MUMPY_WA_DBG): 1 skip q/k/v loads, 2 skip MFMAs+softmax, 4 skip stores
     float scale;
     int64_t units;
@@ -52,10 +58,17 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// load the 16 channels [16h,16h+16) of one 32-channel head row, or zeros
+// load the 16 channels [16h,16h+16) of one 32-channel head row.  Padded rows (token slot >= 49) are CLAMPED to slot 48 by
+// the token table instead of predicated: the duplicates are finite, their scores are overwritten with -1e30 (keys) or
+// never stored (queries), and branch-free loads keep the compiler's vmcnt bookkeeping exact, which the cross-unit
+// prefetch depends on (an exec-masked load made it wait vmcnt(0) and drain the prefetch).
 __device__ __forceinline__ void load_frag(f32x4 (&f)[4], const float* row, bool valid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) f[i] = valid ? *reinterpret_cast<const f32x4*>(row + 4 * i) : f32x4{0, 0, 0, 0};
+}
+__device__ __forceinline__ void load_frag_nb(f32x4 (&f)[4], const float* row) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const f32x4*>(row + 4 * i);
 }
 
 // S^T[jt] += K[jt] Q^T for ONE query tile (32 queries on the lanes); q already scaled
@@ -125,6 +138,11 @@ __device__ __forceinline__ void for_pv_steps(F&& body) {
 }
 
 template <typename VROW>
+__device__ __forceinline__ void load_v_nb(float (&vf)[2][16], VROW vrow, int c, int h) {      // vrow clamps j itself
+    for_pv_steps([&](int jt, int g, int e) { vf[jt][4 * g + e] = vrow(32 * jt + 8 * g + 4 * h + e)[c]; });
+}
+
+template <typename VROW>
 __device__ __forceinline__ void load_v(float (&vf)[2][16], VROW vrow, int c, int h) {
     for_pv_steps([&](int jt, int g, int e) {
         const int j = 32 * jt + 8 * g + 4 * h + e;
@@ -158,34 +176,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     // row-strided reads of it would otherwise cost as many L1 tag cycles as the MFMAs); a (window, head) unit owns its
     // 128-B q/k/v row segments exclusively, so grouping by head costs no extra HBM or L2 traffic.
     const int head = blockIdx.x % a.nH;
-    int64_t bw = (int64_t)(blockIdx.x / a.nH) * 4 + wave;                // window index over the batch
-    const bool active = bw < (int64_t)a.B * a.nW;
-    if (!active) bw = 0;                                                 // idle wave of a ragged last block: loads
-    const int n = (int)(bw % a.nW);                                      // window 0 (valid memory), stores nothing
-    const int64_t b = bw / a.nW;
-    const int wy = n / a.nWx, wx = n - wy * a.nWx;
-    int* tt = tok_tab[wave];
-    tt[lane] = (lane < WT) ? window_token(wy, wx, lane, a.Hs, a.W, a.shift) : 0;
-    __builtin_amdgcn_wave_barrier();
-    const int64_t L = (int64_t)a.Hs * a.W;
-    const float* base = a.qkv + b * L * 3 * a.C + head * HD;
-    const int rs = 3 * a.C;
-
-    // q/k/v go straight to registers and are in flight while the bias table is staged
-    f32x4 qf[2][4], kf[2][4];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int p = 32 * t + c;
-        const bool valid = p < WT;
-        const float* row = base + (int64_t)tt[p & 63] * rs + 16 * h;
-        load_frag(qf[t], row, valid && !(a.dbg & 1));
-        load_frag(kf[t], row + a.C, valid && !(a.dbg & 1));
-    }
-    float vf[2][16];
-    const float* vbase = base + 2 * a.C;
-    if (!(a.dbg & 1)) load_v(vf, [&](int j) { return vbase + (int64_t)tt[j] * rs; }, c, h);
-    else for_pv_steps([&](int jt, int g, int e) { vf[jt][4 * g + e] = 1.f; });
-    {
+    const int slot = blockIdx.x / a.nH;
+    const int64_t nwin = (int64_t)a.B * a.nW;
+    {   // bias table: staged ONCE per persistent block
         const float* bsrc = a.bias + (int64_t)head * 4096;
         for (int idx = threadIdx.x; idx < WT * 16; idx += 256) {
             const int row = idx >> 4, c4 = idx & 15;
@@ -193,6 +186,38 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         }
     }
     __syncthreads();
+    // stagger: the resident waves of a CU would otherwise load, compute and store in lockstep (phases add up instead of
+    // overlapping); a third of the blocks start one third / two thirds of a unit late
+    for (int d = 0; d < (slot % 3) * a.stagger; ++d) __builtin_amdgcn_s_sleep(127);
+    for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {
+    const bool active = true;
+    const int n = (int)(bw % a.nW);                                      // window 0 (valid memory), stores nothing
+    const int64_t b = bw / a.nW;
+    const int wy = n / a.nWx, wx = n - wy * a.nWx;
+    int* tt = tok_tab[wave];
+    tt[lane] = window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);   // padded slots -> slot 48
+    __builtin_amdgcn_wave_barrier();
+    const int64_t L = (int64_t)a.Hs * a.W;
+    const float* base = a.qkv + b * L * 3 * a.C + head * HD;
+    const int rs = 3 * a.C;
+
+    // q/k/v go straight to registers (MFMA operand layout); branch-free
+    f32x4 qf[2][4], kf[2][4];
+    float vf[2][16];
+    if (!(a.dbg & 1)) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float* row = base + (int64_t)tt[32 * t + c] * rs + 16 * h;
+            load_frag_nb(qf[t], row);
+            load_frag_nb(kf[t], row + a.C);
+        }
+        const float* vbase = base + 2 * a.C;
+        load_v_nb(vf, [&](int j) { return vbase + (int64_t)tt[j] * rs; }, c, h);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { load_frag(qf[t], base, false); load_frag(kf[t], base, false); }
+        for_pv_steps([&](int jt, int g, int e) { vf[jt][4 * g + e] = 1.f; });
+    }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -200,7 +225,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
 
     const float* mask_w = nullptr;
     if (a.mask_id) {
-        const int id = a.mask_id[(int)(bw % a.n_mask)];
+        const int id = a.mask_id[__builtin_amdgcn_readfirstlane((int)(bw % a.n_mask))];   // scalar load
         if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
     }
     float* obase = a.out + b * L * a.C + head * HD;
@@ -231,6 +256,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         else { o[0] = s[0][0] + vf[0][0]; o[5] = s[1][2] * vf[1][8]; }
         if (active && !(a.dbg & 4)) store_o(o, it, [&](int i) { return obase + (int64_t)tt[i] * a.C; }, c, h);
         else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1.f;
+    }
+    __builtin_amdgcn_wave_barrier();   // the token table is rewritten by the next unit
     }
 }
 
@@ -319,8 +346,14 @@ extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const fl
     static const int dbgmask = getenv("MUMPY_WA_DBG") ? atoi(getenv("MUMPY_WA_DBG")) : 0;
     a.dbg = dbgmask;
     a.units = (int64_t)B * a.nW * a.nH;
-    const int64_t grid = (((int64_t)B * a.nW + 3) / 4) * a.nH;      // (quads of windows) x heads
-    MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "window_attention: too many windows");
+    // persistent grid: ~3 resident blocks per CU (3 waves/SIMD); each block walks its head's window quads
+    const int64_t quads = ((int64_t)B * a.nW + 3) / 4;
+    static const int wa_blocks = getenv("MUMPY_WA_BLOCKS") ? atoi(getenv("MUMPY_WA_BLOCKS")) : 768;
+    static const int wa_stagger = getenv("MUMPY_WA_STAGGER") ? atoi(getenv("MUMPY_WA_STAGGER")) : 0;
+    int64_t groups = (wa_blocks + a.nH - 1) / a.nH;
+    if (groups > quads) groups = quads;
+    a.groups = (int)groups; a.stagger = wa_stagger;
+    const int64_t grid = groups * a.nH;
     hipLaunchKernelGGL(win_attn_self_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention");
     return 0;
