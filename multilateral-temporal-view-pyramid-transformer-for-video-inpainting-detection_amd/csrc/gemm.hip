@@ -53,7 +53,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     // with NG tiles per group: the blocks resident on an XCD then share a few x row-panels and ONE narrow slice of W, which
     // stay in the 4 MiB L2.  (PMC before this ordering, M=7840 N=2048 K=512: 240 MB fetched for 20 MB of operands --
     // W was re-read from the Infinity Cache for every row panel; profiles/r01_pmc_traffic.md.)
-    constexpr unsigned NG = (BM >= 128) ? 4 : 8;
+    constexpr unsigned NG = (BN >= 128) ? 4 : 8;
     const unsigned nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
     unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const int ks = (int)(wgid % (unsigned)ksplit);       // K slice (split-K): slices of one tile run side by side
@@ -282,13 +282,13 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split) {
     }
     if (force) {
         int ft = -1, fk = -1;
-        if (sscanf(force, "%d,%d", &ft, &fk) >= 1 && (ft == 0 || ft == 2)) {
+        if (sscanf(force, "%d,%d", &ft, &fk) >= 1 && ft >= 0 && ft <= 2) {
             tile = ft;
             if (fk >= 1 && allow_split && K % (32 * fk) == 0) ks = fk; else if (fk >= 1) ks = 1;
         }
     }
     p.tile = tile; p.ksplit = ks;
-    p.gm = (tile == 2) ? gm64 : gm128;
+    p.gm = (tile == 0) ? gm128 : gm64;
     p.gn = (tile == 2) ? gn64 : gn128;
     return p;
 }
@@ -309,9 +309,11 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
     if (conv) {
         if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32, true);
+        else if (p.tile == 1) MUMPY_GEMM(64, 128, 32, 64, true);
         else MUMPY_GEMM(64, 64, 32, 32, true);
     } else {
         if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32, false);
+        else if (p.tile == 1) MUMPY_GEMM(64, 128, 32, 64, false);
         else MUMPY_GEMM(64, 64, 32, 32, false);
     }
 #undef MUMPY_GEMM

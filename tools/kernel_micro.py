@@ -30,6 +30,11 @@ elif op == "sample":
     x2 = torch.randn(b, hs2 * w, c, device=dev); pos = torch.rand(nw, 3, 49, 2, device=dev) * 2 - 1
     fn = lambda: ops.deform_sample(x2, pos, b, hs2, w, c, nw)
     work, unit = 4.0 * (2 * nw * 49 * c + nw * 3 * 49 * 2), "GB/s"
+if op == "ln":
+    rows, c = a
+    x = torch.randn(rows, c, device=dev); g = torch.ones(c, device=dev); b = torch.zeros(c, device=dev)
+    fn = lambda: ops.layernorm(x, g, b)
+    work, unit = 8.0 * rows * c, "GB/s"
 for _ in range(3):
     fn()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
