@@ -218,14 +218,15 @@ def main():
             if i == 0:
                 log("  first decoder forward done")
     log("capturing hipGraph")
-    fwd = None if args.no_graph else GraphedForward(enc, dec, x)
+    fwd = None if args.no_graph else GraphedForward(enc, dec, x, with_mask=True)
     log("timing")
 
-    def step():
+    def step():                     # one forward of the micro-batch, thresholded mask included (fused in the last kernel)
         if fwd is None:
             with torch.no_grad():
-                return dec(*enc(x))[0]
-        return fwd(x)[0]
+                fx, vx, dx = enc(x)
+                return dec.predict_mask(fx, vx, dx)[1]
+        return fwd(x)[1]
 
     for _ in range(2):
         step()
@@ -238,9 +239,9 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        logits = step()
-    # eval tail on device (test.py:100-108) + the ONE collective of the path: all-reduce of the metric vector
-    metric = D.all_reduce_metric(D.eval_metric_vector(ops.sigmoid_threshold(logits), gt))
+        mask = step()
+    # per-image F1/IoU on device (measure.py:57-62,86-89) + the ONE collective of the path: all-reduce of the metric vector
+    metric = D.all_reduce_metric(D.eval_metric_vector(mask, gt))
     barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev)
 

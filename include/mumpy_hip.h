@@ -177,6 +177,12 @@ int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias,
 /* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
 int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);
 
+/* ---- input staging: ToTensor + Normalize + HWC->CHW of the eval pipeline (test.py:22-25)
+ * frames (nframes,H,W,3) uint8 on the DEVICE -> out (nframes,3,H,W) fp32 = (v/255 - mean[c]) / std[c].
+ * mean3 / std3 are HOST pointers to 3 floats (read at launch time). */
+int mumpy_normalize_u8_fwd(const uint8_t* frames, float* out, int64_t nframes, int H, int W, const float* mean3,
+                           const float* std3, void* stream);
+
 /* ---- out = a + b (n floats, n % 4 == 0): the residual add of CrossSwinBlock whose un-added operand is also
  *      consumed by the next view (mTVE:275-276).  out may alias a or b. */
 int mumpy_add_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);

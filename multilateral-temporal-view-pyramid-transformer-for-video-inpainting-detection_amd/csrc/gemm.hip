@@ -31,7 +31,14 @@ struct ConvGeom {
 
 // waves per SIMD the register allocator must leave room for: 8 waves (one block) per CU for the 128x128 tile,
 // 16 waves (four blocks) per CU for the 64x64 tile
-template <int BM, int BN, int WM, int WN, bool CONV>
+// GLDS: stage tiles with global_load_lds (LDS-DMA, 16 B per lane) instead of global_load + ds_write.  A wave-instruction
+// writes 1 KiB linearly = 8 tile rows x 128 B, so the LDS image is UNPADDED [row][32 floats]; bank conflicts are avoided by
+// an XOR swizzle of the 16-B chunk index, chunk' = chunk ^ ((row >> 1) & 7), applied on the SOURCE address (which is
+// per-lane) and again on the fragment reads (cdna guide rule 21: swizzle both sides or neither).  Out-of-image conv taps
+// are fetched from a page of zeros.
+__device__ __attribute__((aligned(128))) float g_zero_page[32];
+
+template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS>
 __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2 : (CONV ? 3 : 4)) void linear_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                      const float* __restrict__ bias, const float* residual,
                                                      float* Y, int64_t M, int N, int K, int act, unsigned gn,
@@ -43,7 +50,8 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     constexpr int A_LD = BM / RPI;                   // float4 loads per thread per chunk
     constexpr int B_LD = BN / RPI;
     static_assert(BM % RPI == 0 && BN % RPI == 0, "tile rows must divide over the staging passes");
-    __shared__ __attribute__((aligned(16))) float lds[2][(BM + BN) * LDR];
+    constexpr int LD = GLDS ? 32 : LDR;              // LDS row stride in dwords
+    __shared__ __attribute__((aligned(1024))) float lds[2][(BM + BN) * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -104,6 +112,36 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
         if (n > N - 1) n = N - 1;
         brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
     }
+    // GLDS: per-lane source chunk (swizzled) for each staged row; the LDS destination of a wave-instruction is linear
+    int asw[A_LD], bsw[B_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) asw[i] = 4 * ((ld_c4 ^ (((ld_row + RPI * i) >> 1) & 7)) - ld_c4);
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) bsw[i] = 4 * ((ld_c4 ^ (((ld_row + RPI * i) >> 1) & 7)) - ld_c4);
+    typedef __attribute__((address_space(1))) const void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto gdma = [&](int k0, int buf) {                           // global -> LDS directly (GLDS)
+        const int wave_row = (tid >> 6) * 8;                     // this wave's 8 rows inside a staging pass
+        if (CONV) {
+            const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
+            const int dy = tap / cg.kw - cg.ph, dx = tap % cg.kw - cg.pw;
+            const int off = (dy * cg.W + dx) * cg.Cin + c0;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const int yy = (ayx[i] >> 16) + dy, xx = (ayx[i] & 0xffff) + dx;
+                const bool ok = (unsigned)yy < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+                const float* src = ok ? arow[i] + off + asw[i] : g_zero_page + 4 * ld_c4;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds[buf][(wave_row + RPI * i) * LD], 16, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i)
+                __builtin_amdgcn_global_load_lds((gptr_t)(arow[i] + k0 + asw[i]), (lptr_t)&lds[buf][(wave_row + RPI * i) * LD], 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(brow[i] + k0 + bsw[i]), (lptr_t)&lds[buf][(BM + wave_row + RPI * i) * LD], 16, 0, 0);
+    };
     auto gload = [&](int k0) {                                   // global -> staging registers (16 B per lane)
         if (CONV) {
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;     // wave-uniform: scalar ALU
@@ -126,22 +164,30 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     auto lstore = [&](int buf) {                                 // staging registers -> LDS tile
 #pragma unroll
         for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<f32x4*>(&lds[buf][(ld_row + RPI * i) * LDR + 4 * ld_c4]) = areg[i];
+            *reinterpret_cast<f32x4*>(&lds[buf][(ld_row + RPI * i) * LD + 4 * ld_c4]) = areg[i];
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<f32x4*>(&lds[buf][(BM + ld_row + RPI * i) * LDR + 4 * ld_c4]) = breg[i];
+            *reinterpret_cast<f32x4*>(&lds[buf][(BM + ld_row + RPI * i) * LD + 4 * ld_c4]) = breg[i];
     };
     auto fread = [&](int buf, f32x4 (&af)[TM][4], f32x4 (&bf)[TN][4]) {   // LDS -> MFMA operand fragments
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            const int R = wm * WM + 32 * i + c;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                af[i][q] = *reinterpret_cast<const f32x4*>(&lds[buf][(wm * WM + 32 * i + c) * LDR + 16 * h + 4 * q]);
+            for (int q = 0; q < 4; ++q) {
+                const int col = GLDS ? 4 * ((4 * h + q) ^ ((R >> 1) & 7)) : 16 * h + 4 * q;
+                af[i][q] = *reinterpret_cast<const f32x4*>(&lds[buf][R * LD + col]);
+            }
+        }
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+            const int R = wn * WN + 32 * j + c;
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                bf[j][q] = *reinterpret_cast<const f32x4*>(&lds[buf][(BM + wn * WN + 32 * j + c) * LDR + 16 * h + 4 * q]);
+            for (int q = 0; q < 4; ++q) {
+                const int col = GLDS ? 4 * ((4 * h + q) ^ ((R >> 1) & 7)) : 16 * h + 4 * q;
+                bf[j][q] = *reinterpret_cast<const f32x4*>(&lds[buf][(BM + R) * LD + col]);
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -168,6 +214,28 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     // so LDS latency, the staging writes and the HBM/L2 latency all sit under MFMA issue.
     const int nk = K / ksplit / BK;
     f32x4 afA[TM][4], bfA[TN][4], afB[TM][4], bfB[TN][4];
+    if (GLDS) {
+        // DMA pipeline, one barrier per chunk: while chunk k's MFMAs issue, chunk k+1's fragments are read from the other
+        // LDS buffer and chunk k+2 is DMA-ed into the buffer chunk k vacated (no staging registers, no ds_write).
+        // __syncthreads() drains the wave's outstanding DMA (hipcc emits vmcnt(0) for it) before the barrier.
+        gdma(kbeg, 0);
+        if (nk > 1) gdma(kbeg + BK, 1);
+        __syncthreads();
+        fread(0, afA, bfA);
+        __syncthreads();                                         // everyone has chunk 0's fragments: buffer 0 is free
+        if (nk > 2) gdma(kbeg + 2 * BK, 0);
+        for (int kc = 0; kc < nk; kc += 2) {
+            if (kc + 1 < nk) fread(1, afB, bfB);
+            mma(afA, bfA);
+            __syncthreads();                                     // chunk kc+2 landed; buffer 1 readers done
+            if (kc + 1 >= nk) break;
+            if (kc + 3 < nk) gdma(kbeg + (kc + 3) * BK, 1);
+            if (kc + 2 < nk) fread(0, afA, bfA);
+            mma(afB, bfB);
+            __syncthreads();
+            if (kc + 4 < nk) gdma(kbeg + (kc + 4) * BK, 0);
+        }
+    } else {
     gload(kbeg);
     lstore(0);
     if (nk > 1) gload(kbeg + BK);
@@ -188,6 +256,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
         if (kc + 3 < nk && !(dbg & 2)) lstore(1);
         if (kc + 4 < nk && !(dbg & 1)) gload(kbeg + (kc + 4) * BK);
         if (!(dbg & 8)) __syncthreads();
+    }
     }
     if (dbg & 16) { if (acc[0][0][0] == 12345.678f) Y[0] = 1.f; return; }
 
@@ -303,10 +372,16 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
 #define MUMPY_GEMM(BM_, BN_, WM_, WN_, CV_)                                                                        \
-    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_, CV_>), dim3((unsigned)grid),                               \
+    if (use_glds)                                                                                                  \
+        hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_, CV_, true>), dim3((unsigned)grid),                     \
+                           dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, s, x, W, bias, residual, y, M, N, K, act, p.gn,  \
+                           p.ksplit, ws, rpb, bstride, dbgmask, cg);                                               \
+    else                                                                                                           \
+    hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_, CV_, false>), dim3((unsigned)grid),                        \
                        dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, s, x, W, bias, residual, y, M, N, K, act, p.gn, p.ksplit, \
                        ws, rpb, bstride, dbgmask, cg)
     static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
+    static const bool use_glds = getenv("MUMPY_GEMM_GLDS") ? atoi(getenv("MUMPY_GEMM_GLDS")) != 0 : false;
     if (conv) {
         if (p.tile == 0) MUMPY_GEMM(128, 128, 64, 32, true);
         else if (p.tile == 1) MUMPY_GEMM(64, 128, 32, 64, true);

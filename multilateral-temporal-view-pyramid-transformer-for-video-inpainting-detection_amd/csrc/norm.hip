@@ -146,3 +146,45 @@ extern "C" int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, i
     MUMPY_CHECK_LAUNCH("sigmoid_threshold");
     return 0;
 }
+
+// ------------------------------------------------------------------ input staging
+// ToTensor + Normalize of the eval pipeline (test.py:22-25; torchvision semantics: u8/255, then (v - mean)/std per
+// channel) fused with the HWC -> CHW transpose: frames (N,H,W,3) uint8 -> clip tensor (N,3,H,W) fp32.
+// A thread converts 4 consecutive pixels of one channel: 16-B coalesced store; the 12 source bytes come from L1.
+namespace {
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                           int64_t nframes, int64_t HW, float m0, float m1, float m2,
+                                                           float s0, float s1, float s2) {
+    const int64_t q4 = HW >> 2;
+    const int64_t total = nframes * 3 * q4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t p4 = i % q4;
+        const int64_t t = i / q4;
+        const int ch = (int)(t % 3);
+        const int64_t f = t / 3;
+        const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+        const float stdv = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+        const uint8_t* s = src + (f * HW + 4 * p4) * 3 + ch;
+        f32x4 v;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((float)s[3 * k] / 255.0f - mean) / stdv;
+        *reinterpret_cast<f32x4*>(dst + (f * 3 + ch) * HW + 4 * p4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int mumpy_normalize_u8_fwd(const uint8_t* frames, float* out, int64_t nframes, int H, int W, const float* mean3,
+                                      const float* std3, void* stream) {
+    MUMPY_REQUIRE(frames && out && mean3 && std3, MUMPY_ENULL, "normalize_u8: null pointer");
+    MUMPY_REQUIRE(nframes >= 0 && H > 0 && W > 0 && ((int64_t)H * W) % 4 == 0, MUMPY_EINVAL, "normalize_u8: H*W must be a multiple of 4");
+    MUMPY_REQUIRE(aligned16(out), MUMPY_EALIGN, "normalize_u8: out must be 16-byte aligned");
+    MUMPY_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, MUMPY_EINVAL, "normalize_u8: zero std");
+    if (nframes == 0) return 0;
+    const int64_t total = nframes * 3 * ((int64_t)H * W / 4);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(normalize_u8_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), frames, out, nframes,
+                       (int64_t)H * W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    MUMPY_CHECK_LAUNCH("normalize_u8");
+    return 0;
+}

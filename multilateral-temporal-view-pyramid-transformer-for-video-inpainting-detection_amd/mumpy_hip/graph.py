@@ -5,8 +5,10 @@ import torch
 
 
 class GraphedForward:
-    def __init__(self, encoder, decoder, example: torch.Tensor, warmup: int = 2):
-        self.encoder, self.decoder = encoder, decoder
+    def __init__(self, encoder, decoder, example: torch.Tensor, warmup: int = 2, with_mask: bool = False):
+        """with_mask=True captures Decoder.predict_mask: outputs are (logits, uint8 mask, feats), the thresholded mask
+        of test.py:100-108 coming out of the same last kernel."""
+        self.encoder, self.decoder, self.with_mask = encoder, decoder, with_mask
         self.static_x = example.clone()
         side = torch.cuda.Stream(device=example.device)
         side.wait_stream(torch.cuda.current_stream())
@@ -21,7 +23,7 @@ class GraphedForward:
 
     def _fwd(self):
         fx, vx, dx = self.encoder(self.static_x)
-        return self.decoder(fx, vx, dx)
+        return self.decoder.predict_mask(fx, vx, dx) if self.with_mask else self.decoder(fx, vx, dx)
 
     def __call__(self, x: torch.Tensor):
         """Returns the static (logits, feats) buffers; contents are overwritten by the next call."""

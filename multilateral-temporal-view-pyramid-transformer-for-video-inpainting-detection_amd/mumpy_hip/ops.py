@@ -329,3 +329,22 @@ def sigmoid_threshold(logits, thr=0.5):
     mask = torch.empty(logits.shape, device=logits.device, dtype=torch.uint8)
     _call("mumpy_sigmoid_threshold_fwd", _p(logits), _p(mask), logits.numel(), thr, _stream())
     return mask
+
+
+EVAL_MEAN, EVAL_STD = (0.4776, 0.479, 0.4465), (0.230, 0.2085, 0.2324)      # test.py:23-24
+
+
+def normalize_u8(frames, mean=EVAL_MEAN, std=EVAL_STD):
+    """frames (..., H, W, 3) uint8 on the GPU -> (..., 3, H, W) float32, ToTensor + Normalize (test.py:22-25)."""
+    import ctypes
+    if not frames.is_cuda or frames.dtype != torch.uint8 or frames.shape[-1] != 3:
+        raise RuntimeError("mumpy_hip: normalize_u8 needs a uint8 GPU tensor (..., H, W, 3) (there is no CPU path)")
+    frames = frames.contiguous()
+    lead, (h, w) = frames.shape[:-3], frames.shape[-3:-1]
+    n = 1
+    for d in lead:
+        n *= d
+    out = torch.empty(*lead, 3, h, w, device=frames.device, dtype=torch.float32)
+    m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+    _call("mumpy_normalize_u8_fwd", _p(frames), _p(out), n, h, w, m3, s3, _stream(), work=float(frames.numel() + 4 * out.numel()))
+    return out

@@ -306,6 +306,17 @@ def test_linear_rows_strided_time_slices():
     assert rel_err(y.cpu(), ref) < 1e-5
 
 
+def test_normalize_u8_input_staging():
+    """ToTensor + Normalize(mean, std) of test.py:22-25 fused with HWC->CHW, on device."""
+    g = torch.Generator().manual_seed(3)
+    frames = torch.randint(0, 256, (2, 3, 224, 224, 3), generator=g, dtype=torch.uint8)
+    out = ops.normalize_u8(frames.to(DEV)).cpu()
+    mean, std = torch.tensor(ops.EVAL_MEAN).view(1, 1, 3, 1, 1), torch.tensor(ops.EVAL_STD).view(1, 1, 3, 1, 1)
+    ref = (frames.permute(0, 1, 4, 2, 3).float() / 255.0 - mean) / std
+    assert out.shape == (2, 3, 3, 224, 224)
+    assert rel_err(out, ref) < 1e-6
+
+
 def test_sigmoid_threshold():
     z = seeded_randn(4, 2, 1, 224, 224)
     z[0, 0, 0, :4] = torch.tensor([0.0, 1e-7, -1e-7, 30.0])
@@ -413,6 +424,53 @@ def test_predict_mask_fused_tail(model_t3):
     # final conv vs torch on the same features
     ref = F.conv2d(feats.cpu().double(), dec.final_out.weight.cpu().double(), dec.final_out.bias.cpu().double(), padding=1)
     assert rel_err(logits.cpu(), ref) < 1e-5
+
+
+def test_eval_step_from_uint8_frames(model_t3):
+    """uint8 frames -> on-device normalisation -> forward -> fused mask -> metric vector."""
+    from mumpy_hip.evaluate import eval_step, finalize_metrics
+    enc, dec = model_t3
+    g = torch.Generator().manual_seed(11)
+    frames = torch.randint(0, 256, (2, 3, 224, 224, 3), generator=g, dtype=torch.uint8)
+    gt = torch.rand(2, 1, 224, 224, generator=g) < 0.2
+    mask, logits, metric = eval_step(enc, dec, frames.to(DEV), gt.to(DEV))
+    x = ops.normalize_u8(frames.to(DEV))
+    with torch.no_grad():
+        ref_logits = dec(*enc(x))[0]
+    assert torch.equal(logits, ref_logits)
+    ref_metric = O.metric_vector(O.mask_from_logits(ref_logits.cpu()), gt)
+    assert torch.allclose(metric.cpu(), ref_metric, rtol=1e-12, atol=1e-12)
+    f1, iou, n = finalize_metrics(metric)
+    assert n == 2 and 0.0 <= f1 <= 1.0 and 0.0 <= iou <= 1.0
+
+
+def test_gemm_lds_dma_variant_in_subprocess():
+    """The LDS-DMA (global_load_lds) staging variant of the GEMM/conv kernel is selected by MUMPY_GEMM_GLDS=1 (read once
+    per process): run a few shapes in a child process and compare with fp64."""
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    code = r'''
+import sys, torch
+sys.path[:0] = [%r, %r]
+from mumpy_hip import ops
+import torch.nn.functional as F
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(1)
+for m, n, k in [(300, 128, 96), (1568, 384, 1536), (7840, 512, 512)]:
+    x = torch.randn(m, k, generator=g); w = torch.randn(n, k, generator=g) / k ** 0.5; b = torch.randn(n, generator=g)
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev), act=1).cpu().double()
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double()))
+    assert float((y - ref).abs().max() / ref.abs().max()) < 1e-5, (m, n, k)
+x = torch.randn(2, 64, 14, 14, generator=g); w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+y = ops.conv2d_nhwc(x.to(dev).contiguous(memory_format=torch.channels_last), w.permute(0, 2, 3, 1).contiguous().to(dev)).cpu().double()
+ref = F.conv2d(x.double(), w.double(), padding=1)
+assert float((y - ref).abs().max() / ref.abs().max()) < 1e-5
+print("ok")
+''' % (PKG, ROOT)
+    env = dict(os.environ, MUMPY_GEMM_GLDS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
 
 
 def test_strict_checkpoint_roundtrip(tmp_path, model_t3):
