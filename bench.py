@@ -198,6 +198,7 @@ def main():
     from models.encoder.encoder import Encoder
     from mumpy_hip import ops
     from mumpy_hip.graph import GraphedForward
+    from mumpy_hip.pipeline import fused_forward
     from weight_fill import fill_module_, seeded_randn
 
     log("building model + synthetic weights")
@@ -223,9 +224,7 @@ def main():
 
     def step():                     # one forward of the micro-batch, thresholded mask included (fused in the last kernel)
         if fwd is None:
-            with torch.no_grad():
-                fx, vx, dx = enc(x)
-                return dec.predict_mask(fx, vx, dx)[1]
+            return fused_forward(enc, dec, x, with_mask=True)[1]
         return fwd(x)[1]
 
     for _ in range(2):

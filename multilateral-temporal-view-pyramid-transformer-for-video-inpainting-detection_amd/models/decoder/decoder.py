@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from models.modules.layers import Derived
 from mumpy_hip import ops
+from mumpy_hip.streams import run_parallel
 
 
 class SEB(nn.Module):
@@ -182,31 +183,59 @@ class Decoder(nn.Module):
         return ops.gn_apply_resample(x, g, act=ops.ACT_RELU, mean4=mean4, scale=2, align_corners=True, ep_mode=ep_mode,
                                      ep_a=ep_a, ep_b=ep_b)
 
-    def _features(self, x, view_x, ffinfo):
-        """Everything up to DAP: -> x_feats (B,32,224,224), NHWC memory."""
-        rgb1, rgb2, rgb3, rgb4 = [self._rgb_head(i, view_x[i], self.shape[i]) for i in range(4)]
-        b, dev = x.shape[0], x.device
-        freq0 = self._freq(self.decoder_frequency_0, ffinfo.contiguous(memory_format=torch.channels_last))
-        freq1 = self._freq(self.decoder_frequency_1, freq0)
-        freq2 = self._freq(self.decoder_frequency_2, freq1)
-        freq3 = self._freq(self.decoder_frequency_3, freq2)
-        freq4 = self._freq(self.decoder_frequency_4, freq3)
+    def _branches(self, view_x, ffinfo):
+        """Everything that does not need the encoder's final tokens: frequency pyramid, the four temporal heads and the
+        SEB/GCM pyramids 2-4.  Independent chains of small kernels are forked onto side streams."""
+        b, dev = ffinfo.shape[0], ffinfo.device
+
+        def freq_chain():
+            f0 = self._freq(self.decoder_frequency_0, ffinfo.contiguous(memory_format=torch.channels_last))
+            f1 = self._freq(self.decoder_frequency_1, f0)
+            f2 = self._freq(self.decoder_frequency_2, f1)
+            f3 = self._freq(self.decoder_frequency_3, f2)
+            return [f0, f1, f2, f3, self._freq(self.decoder_frequency_4, f3)]
+
+        flat = [t for stage in view_x for t in stage]
+        (rgb3, rgb4), (rgb2,), freq, (rgb1,) = run_parallel(
+            [lambda: [self._rgb_head(2, view_x[2], self.shape[2]), self._rgb_head(3, view_x[3], self.shape[3])],
+             lambda: [self._rgb_head(1, view_x[1], self.shape[1])],
+             freq_chain,
+             lambda: [self._rgb_head(0, view_x[0], self.shape[0])]],
+            [flat, flat, (ffinfo,), flat])
+
+        def pyr1():
+            return [self._gcm(self.gcm2, self._seb(self.seb1, rgb3, rgb4))]
+
+        def pyr2():
+            cat2 = ops.empty_nhwc(b, 512, 14, 14, dev)                 # [rgb3 | up2(rgb4)]          (decoder.py:210)
+            cat2[:, :256] = rgb3
+            self._up(rgb4, 2, out=cat2, out_coff=256)
+            return [self._gcm(self.gcm3, self._seb(self.seb2, rgb2, cat2))]
+
+        def pyr3():
+            cat3 = ops.empty_nhwc(b, 768, 28, 28, dev)                 # [rgb2 | up2(rgb3) | up4(rgb4)] (decoder.py:213)
+            cat3[:, :256] = rgb2
+            self._up(rgb3, 2, out=cat3, out_coff=256)
+            self._up(rgb4, 4, out=cat3, out_coff=512)
+            return [self._gcm(self.gcm4, self._seb(self.seb3, rgb1, cat3))]
+
+        deps = (rgb1, rgb2, rgb3, rgb4)
+        (gcn1,), (gcn2,), (gcn3,) = run_parallel([pyr1, pyr2, pyr3], [deps, deps, deps])
+        return {"rgb4": rgb4, "freq": freq, "gcn": (gcn1, gcn2, gcn3)}
+
+    def _trunk(self, x, br):
+        """gcm1 on [rgb4 | final tokens] and the sequential decoder_2..5 trunk -> x_feats (B,32,224,224), NHWC memory."""
+        freq0, freq1, freq2, freq3, freq4 = br["freq"]
+        gcn1, gcn2, gcn3 = br["gcn"]
         x = x.contiguous(memory_format=torch.channels_last)
-        out1 = self.ecre(self._gcm(self.gcm1, torch.cat([rgb4, x], dim=1)) * freq4)
-        gcn1 = self._gcm(self.gcm2, self._seb(self.seb1, rgb3, rgb4))
-        cat2 = ops.empty_nhwc(b, 512, 14, 14, dev)                     # [rgb3 | up2(rgb4)]          (decoder.py:210)
-        cat2[:, :256] = rgb3
-        self._up(rgb4, 2, out=cat2, out_coff=256)
-        gcn2 = self._gcm(self.gcm3, self._seb(self.seb2, rgb2, cat2))
-        cat3 = ops.empty_nhwc(b, 768, 28, 28, dev)                     # [rgb2 | up2(rgb3) | up4(rgb4)] (decoder.py:213)
-        cat3[:, :256] = rgb2
-        self._up(rgb3, 2, out=cat3, out_coff=256)
-        self._up(rgb4, 4, out=cat3, out_coff=512)
-        gcn3 = self._gcm(self.gcm4, self._seb(self.seb3, rgb1, cat3))
+        out1 = self.ecre(self._gcm(self.gcm1, torch.cat([br["rgb4"], x], dim=1)) * freq4)
         z = self._dec(self.decoder_2, gcn1 * freq3 + out1, ops.EP_ADD_MUL, gcn2, freq2)     # = decoder_3's input
         z = self._dec(self.decoder_3, z, ops.EP_ADD_MUL, gcn3, freq1)                       # = decoder_4's input
         z = self._dec(self.decoder_4, z, ops.EP_MUL, freq0)                                 # = decoder_5's input
         return self._dec(self.decoder_5, z, mean4=True)                                     # DAP folded in
+
+    def _features(self, x, view_x, ffinfo):
+        return self._trunk(x, self._branches(view_x, ffinfo))
 
     def _final_weight(self):
         return self._cached(("wf",), (self.final_out.weight,), lambda: self.final_out.weight.permute(0, 2, 3, 1).contiguous())

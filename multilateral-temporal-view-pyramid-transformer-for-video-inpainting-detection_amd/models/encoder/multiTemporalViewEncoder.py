@@ -17,6 +17,7 @@ from models.modules.deformableAttention import SwinDAttention
 from models.modules.layers import Derived, DropPath, to_2tuple, trunc_normal_
 from models.modules.swinTransformer import Mlp, SwinTransformerBlock, ThreeViewPatchMerging, WindowAttention
 from mumpy_hip import ops
+from mumpy_hip.streams import run_parallel
 
 
 class CVAModule(nn.Module):
@@ -135,13 +136,22 @@ class MultiViewBasicLayer(nn.Module):
         self.blocks = nn.ModuleList(blocks)
         self.downsample = downsample(view_configs, cur_stage) if downsample is not None else None
 
-    def forward(self, x):
-        for blk in self.blocks:
-            x = blk(x)
-        out = list(x)                                       # features BEFORE the downsample feed the decoder (mTVE:535)
+    def _view_chain(self, v, x):
+        """Blocks 1..d-1 of view v (independent of the other views, mTVE:445-450) and its patch merging."""
+        for blk in self.blocks[1:]:
+            x = getattr(blk, f"block{v + 1}")(x)
+        out = x                                             # features BEFORE the downsample feed the decoder (mTVE:535)
         if self.downsample is not None:
-            x = self.downsample(x)
+            x = getattr(self.downsample, f"downsample{v + 1}")(x)
         return x, out
+
+    def forward(self, x):
+        x = self.blocks[0](x)                               # cross-view block: view 3 -> 2 -> 1 dependency chain
+        # the three views are independent from here to the end of the stage: fork them (view 3, the heaviest, stays on
+        # the current stream)
+        res = run_parallel([lambda: self._view_chain(0, x[0]), lambda: self._view_chain(1, x[1]),
+                            lambda: self._view_chain(2, x[2])], [(x[0],), (x[1],), (x[2],)])
+        return [r[0] for r in res], [r[1] for r in res]
 
 
 class CreateStages(nn.Module):
@@ -230,16 +240,24 @@ class ThreeViewSwinTransformer(nn.Module):
             parts.append(x.expand(b, tmax, l // t, c) if t == 1 else x.repeat(1, tmax // t, 1, 1))
         return torch.cat(parts, dim=-1)
 
-    def forward(self, x):
-        """x (B,T,3,224,224) -> (tokens (B,49,2304), view_x[4][3] of (B,1,L,C), dct (B,9,224,224))."""
-        b = x.shape[0]
-        ffinfo = self.faf.forward_frame(x, 1)                                  # frame index 1 only (mTVE:734)
-        views, stage_out = self.layers(self.tokenize(x))
+    def forward_stages(self, x):
+        """DCT branch + tokenizer + the four pyramid stages -> (views after stage 3, per-stage features, dct)."""
+        # the DCT branch is independent of the token path until the decoder: fork it (frame index 1 only, mTVE:734)
+        (ffinfo,), (views, stage_out) = run_parallel(
+            [lambda: (self.faf.forward_frame(x, 1),), lambda: self.layers(self.tokenize(x))], [(x,), (x,)])
+        return views, [[v.unsqueeze(1) for v in stage] for stage in stage_out], ffinfo
+
+    def forward_global(self, views):
+        """Channel-merge of the views + the 12 temporal ViT blocks -> tokens (B,49,2304)."""
+        b = views[0].shape[0]
         g = self.merge_views_along_channel_axis(views)                         # (B,T,49,2560)
         t = g.shape[1]
         g = g.permute(0, 2, 1, 3).reshape(b * 49, t, g.shape[-1])              # one T-token sequence per site
         g = ops.linear(g, self.globalembedding.weight, self.globalembedding.bias)
         g = self.globalblocks(g).reshape(b, 49, t, 768)
-        final = g[:, :, :3].reshape(b, 49, 3 * 768)                            # frames 0,1,2 on channels (mTVE:745)
-        out_x = [[v.unsqueeze(1) for v in stage] for stage in stage_out]
-        return final, out_x, ffinfo
+        return g[:, :, :3].reshape(b, 49, 3 * 768)                             # frames 0,1,2 on channels (mTVE:745)
+
+    def forward(self, x):
+        """x (B,T,3,224,224) -> (tokens (B,49,2304), view_x[4][3] of (B,1,L,C), dct (B,9,224,224))."""
+        views, out_x, ffinfo = self.forward_stages(x)
+        return self.forward_global(views), out_x, ffinfo

@@ -22,8 +22,8 @@ class GraphedForward:
             self.static_out = self._fwd()
 
     def _fwd(self):
-        fx, vx, dx = self.encoder(self.static_x)
-        return self.decoder.predict_mask(fx, vx, dx) if self.with_mask else self.decoder(fx, vx, dx)
+        from .pipeline import fused_forward
+        return fused_forward(self.encoder, self.decoder, self.static_x, with_mask=self.with_mask)
 
     def __call__(self, x: torch.Tensor):
         """Returns the static (logits, feats) buffers; contents are overwritten by the next call."""

@@ -403,6 +403,22 @@ def test_full_model_t9_vs_oracle():
     assert rel_err(fx.cpu(), ref[2]) < TOL
 
 
+def test_full_model_b16_t5_vs_oracle():
+    """Twice the benchmark micro-batch (B=16, T=5): guards index widths / grid limits beyond the bench shape.
+    Checked against the oracle on the host (micro-batch coupling included, so the whole batch is one oracle call)."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = seeded_randn(1616, 16, 5, 3, 224, 224)
+    with torch.no_grad():
+        fx, vx, dx = enc(x.to(DEV))
+        logits, _ = dec(fx, vx, dx)
+        ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)
+    assert rel_err(logits.cpu(), ref[0]) < TOL
+    assert rel_err(fx.cpu(), ref[2]) < TOL
+
+
 def test_baseline_encoder(full_golden):
     from models.encoder.encoder import BaselineEncoder
     enc = _load_filled(BaselineEncoder(), DEV)
@@ -504,6 +520,19 @@ def test_hip_graph_replay_is_identical(model_t3):
         if seed == 78:
             g = GraphedForward(enc, dec, x)
         assert torch.equal(g(x)[0], eager)
+
+
+def test_fused_pipeline_matches_sequential_calls(model_t3):
+    """mumpy_hip.pipeline.fused_forward (global blocks || decoder branches) == Decoder()(*Encoder()(x)), bit for bit."""
+    from mumpy_hip.pipeline import fused_forward
+    enc, dec = model_t3
+    x = seeded_randn(82, 2, 3, 3, 224, 224).to(DEV)
+    with torch.no_grad():
+        logits, feats = dec(*enc(x))
+    l2, mask, f2 = fused_forward(enc, dec, x, with_mask=True)
+    torch.cuda.synchronize()
+    assert torch.equal(l2, logits) and torch.equal(f2, feats)
+    assert torch.equal(mask.cpu(), O.mask_from_logits(logits.cpu()))
 
 
 def test_encoder_graph_replay_bit_exact(model_t3):
