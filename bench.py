@@ -192,6 +192,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # host threads: N ranks build their weights concurrently on one node; keep each within its share of the cores
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     from mumpy_hip import distributed as D
     D.init_process_group("nccl", dev)                        # RCCL over xGMI (no-op at world 1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"

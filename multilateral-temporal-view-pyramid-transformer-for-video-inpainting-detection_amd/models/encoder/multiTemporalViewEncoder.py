@@ -59,24 +59,33 @@ class CrossSwinBlock(nn.Module):
                                  attn_drop, drop_path, cur_stage)
         self.register_buffer("attn_mask", None)
 
-    def forward(self, x1, x2):
-        """x1 (B, t1*H*W, C1), x2 (B, t2*H*W, C2) raster.  Returns (x1_new, out) with out = the W-MSA output BEFORE
-        the residual, which is what the next view consumes (mTVE:275, 347-349)."""
+    def msa(self, x1):
+        """First half: x1 + W-MSA(LN(x1)).  Returns (x1 after the residual, out = W-MSA output BEFORE the residual, which is
+        what the next view's cross attention consumes: mTVE:275, 347-349)."""
+        h, w = self.input_resolution
+        b, l1, c1 = x1.shape
+        self.drop_path(x1)
+        a = self.attn.attend(ops.layernorm(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, l1 // w, w, 0, None)
+        out = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
+        return ops.add(x1, out), out
+
+    def tail(self, x1, x2):
+        """Second half: deformable cross-view attention against x2 (skipped for the last view) and the MLP."""
         h, w = self.input_resolution
         b, l1, c1 = x1.shape
         hs1 = l1 // w
-        self.drop_path(x1)
-        a = self.attn.attend(ops.layernorm(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs1, w, 0, None)
-        out = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
-        x1 = ops.add(x1, out)
         if not self.last_view:
             hs2 = x2.shape[1] // w
             x2p = ops.linear(x2, self.pre.weight, self.pre.bias)                    # per-token, raster (mTVE:283)
             yt = self.cva.crossattn.attend_raster(x1, x2p, b, hs1, w, hs2)
             # x1 + [x1 in window order] + [scrambled proj_out]  (mTVE:138, 285-286; deform:403)
             x1 = ops.deform_combine(x1, yt, b, hs1, w, c1)
-        x1 = self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1)
-        return x1, out
+        return self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1)
+
+    def forward(self, x1, x2):
+        """x1 (B, t1*H*W, C1), x2 (B, t2*H*W, C2) raster.  Returns (x1_new, out)."""
+        x1, out = self.msa(x1)
+        return self.tail(x1, x2), out
 
 
 class CrossThreeViewSwinBlock(nn.Module):
@@ -96,9 +105,48 @@ class CrossThreeViewSwinBlock(nn.Module):
                                      temporal_dims=3, **kw)
 
     def forward(self, x):
-        x3, out3 = self.block3(x[2], x[2])
-        x2, out2 = self.block2(x[1], out3)
-        x1, _ = self.block1(x[0], out2)
+        """Reference order (mTVE:345-350): block3(x3) -> block2(x2, out3) -> block1(x1, out2).  The three W-MSA halves are
+        independent and a view's cross attention needs only the NEXT view's W-MSA output, so the block runs as three
+        branches with two cross-branch events:
+            current stream:  msa3 --(out3)--> mlp3
+            side A:          msa2 --(out2)--> [wait out3] cva2 + mlp2
+            side B:          msa1 ----------> [wait out2] cva1 + mlp1                                             """
+        from mumpy_hip import streams
+        if streams.SERIAL:
+            x3, out3 = self.block3(x[2], x[2])
+            x2, out2 = self.block2(x[1], out3)
+            x1, _ = self.block1(x[0], out2)
+            return [x1, x2, x3]
+        main = torch.cuda.current_stream()
+        sa, sb = streams._side_stream(main.device, 0), streams._side_stream(main.device, 1)
+        fork, e3, e2 = torch.cuda.Event(), torch.cuda.Event(), torch.cuda.Event()
+        fork.record(main)
+        streams._DEPTH[0] += 1
+        try:
+            x3a, out3 = self.block3.msa(x[2])
+            e3.record(main)
+            sa.wait_event(fork)
+            x[1].record_stream(sa)
+            with torch.cuda.stream(sa):
+                x2a, out2 = self.block2.msa(x[1])
+                e2.record(sa)
+                sa.wait_event(e3)
+                out3.record_stream(sa)
+                x2 = self.block2.tail(x2a, out3)
+            sb.wait_event(fork)
+            x[0].record_stream(sb)
+            with torch.cuda.stream(sb):
+                x1a, _ = self.block1.msa(x[0])
+                sb.wait_event(e2)
+                out2.record_stream(sb)
+                x1 = self.block1.tail(x1a, out2)
+            x3 = self.block3.tail(x3a, None)
+        finally:
+            streams._DEPTH[0] -= 1
+        main.wait_stream(sa)
+        main.wait_stream(sb)
+        x2.record_stream(main)
+        x1.record_stream(main)
         return [x1, x2, x3]
 
 
