@@ -32,6 +32,7 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests", "golden")):
         sys.path.insert(0, p)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32)
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense bf16 matrix peak
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 HBM_BOUND = {"mumpy_deform_sample_fwd", "mumpy_layernorm_fwd", "mumpy_gn_stats_nhwc_fwd", "mumpy_gn_apply_resample_nhwc_fwd", "mumpy_final_conv_fwd", "mumpy_patch_merge_ln_fwd",
              "mumpy_add_fwd"}
@@ -54,6 +55,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (micro-batch)")
     ap.add_argument("--frames", type=int, default=5)
+    ap.add_argument("--math", choices=["fp32", "bf16"], default="fp32",
+                    help="matrix arithmetic of the GEMMs/convolutions: fp32 (headline, default) or bf16 operands + fp32 accumulate")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -205,6 +208,7 @@ def main():
     from mumpy_hip.pipeline import fused_forward
     from weight_fill import fill_module_, seeded_randn
 
+    ops.set_matrix_math(args.math)
     log("building model + synthetic weights")
     enc = fill_module_(Encoder(num_frames=args.frames).eval()).to(dev)
     dec = fill_module_(Decoder(input_token_temporal_dims=[1, 1, args.frames]).eval()).to(dev)
@@ -259,7 +263,8 @@ def main():
         out = {
             "metric": "clips/sec fwd (B=8,T=5,224x224)", "value": round(clips / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.math == "fp32" else "bf16 matrix operands, f32 accumulate and storage", "data": "synthetic",
             "config": {"workload": f"full Mumpy forward (3 temporal views, pyramid decoder), B={args.batch} clips/GPU, "
                                    f"T={args.frames}, 224x224, fp32, tubelets ({args.frames},{args.frames - 1},1)",
                        "global_batch": args.batch * world, "launch": ("eager" if fwd is None else "hipGraph replay") + ", fork/join over HIP streams (independent branches co-scheduled)",

@@ -35,6 +35,10 @@ extern "C" {
 /* activation selector for mumpy_linear_fwd */
 #define MUMPY_ACT_NONE 0
 #define MUMPY_ACT_GELU 1    /* exact erf GELU, as nn.GELU() */
+/* OR-ed into `act` of the linear / conv entry points: round x and W to bf16 while staging and multiply on the bf16
+ * MFMA (fp32 accumulate, fp32 bias/activation/residual, fp32 tensors in memory).  Config 3's matrix arithmetic; the
+ * default (flag absent) is exact fp32 on v_mfma_f32_32x32x2_f32. */
+#define MUMPY_MATH_BF16 0x100
 
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);

@@ -310,6 +310,173 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// bf16 MATRIX-MATH mode (MUMPY_MATH_BF16): tensors stay fp32 in HBM; x and W are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) while they are staged into LDS, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16 (16x the
+// fp32 MFMA rate), bias / GELU / residual stay fp32.  This is config 3's arithmetic ("bf16 operands, fp32 accumulate")
+// applied to the GEMMs and convolutions only; it turns them from MFMA-bound into staging/HBM-bound.
+// LDS rows hold 32 bf16 (16 dwords) padded to 20 dwords: conflict-free ds_read_b128 (one 8-element fragment per lane
+// per 16-deep MFMA step).  Same tiles / planner / split-K / implicit-GEMM addressing as the fp32 kernel.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = 20;
+
+template <int BM, int BN, int WM, int WN, bool CONV>
+__global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
+                                                            const float* __restrict__ bias, const float* residual,
+                                                            float* Y, int64_t M, int N, int K, int act, unsigned gn,
+                                                            int ksplit, float* slab, int64_t rpb, int64_t bstride,
+                                                            ConvGeom cg) {
+    constexpr int TM = WM / 32, TN = WN / 32;
+    constexpr int WAVES_N = BN / WN;
+    static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
+    constexpr int RPI = 32, A_LD = BM / RPI, B_LD = BN / RPI;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(BM + BN) * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    constexpr unsigned NG = (BN >= 128) ? 4 : 8;
+    const unsigned nwg = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    unsigned wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+    const int ks = (int)(wgid % (unsigned)ksplit);
+    wgid /= (unsigned)ksplit;
+    const unsigned gm = (unsigned)((M + BM - 1) / BM);
+    const unsigned full = (gn / NG) * NG;
+    unsigned tm, tn;
+    if (wgid < gm * full) {
+        const unsigned grp = wgid / (gm * NG), rem = wgid - grp * gm * NG;
+        tm = rem / NG; tn = grp * NG + rem % NG;
+    } else {
+        const unsigned wdt = gn - full, rem = wgid - gm * full;
+        tm = rem / wdt; tn = full + rem % wdt;
+    }
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = (int)tn * BN;
+    const int kbeg = ks * (K / ksplit);
+    const int ld_row = tid >> 3, ld_c4 = tid & 7;
+    f32x4 areg[A_LD], breg[B_LD];
+    const float* arow[A_LD];
+    const float* brow[B_LD];
+    int ayx[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        int64_t m = m0 + ld_row + RPI * i;
+        if (m > M - 1) m = M - 1;
+        if (CONV) {
+            ayx[i] = ((int)((m / cg.W) % cg.H) << 16) | (int)(m % cg.W);
+            arow[i] = X + m * cg.Cin + 4 * ld_c4;
+        } else {
+            ayx[i] = 0;
+            arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < B_LD; ++i) {
+        int n = n0 + ld_row + RPI * i;
+        if (n > N - 1) n = N - 1;
+        brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
+    }
+    auto gload = [&](int k0) {
+        if (CONV) {
+            const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
+            const int dy = tap / cg.kw - cg.ph, dx = tap % cg.kw - cg.pw;
+            const int off = (dy * cg.W + dx) * cg.Cin + c0;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const int yy = (ayx[i] >> 16) + dy, xx = (ayx[i] & 0xffff) + dx;
+                const bool ok = (unsigned)yy < (unsigned)cg.H && (unsigned)xx < (unsigned)cg.W;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(arow[i] + (ok ? off : 0));
+                areg[i] = ok ? v : f32x4{0, 0, 0, 0};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
+    };
+    auto pack = [](const f32x4& v) -> uint2 {
+        bf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
+        return *reinterpret_cast<uint2*>(&b);
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            *reinterpret_cast<uint2*>(&lds[buf][(ld_row + RPI * i) * LDH + 2 * ld_c4]) = pack(areg[i]);
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i)
+            *reinterpret_cast<uint2*>(&lds[buf][(BM + ld_row + RPI * i) * LDH + 2 * ld_c4]) = pack(breg[i]);
+    };
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = K / ksplit / BK;
+    gload(kbeg);
+    lstore(0);
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) gload(kbeg + (kc + 1) * BK);
+        bf16x8 af[TM][2], bf[TN][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)      // MFMA step st: k = 16 st + 8 h + j (A/B operand maps of 32x32x16 bf16)
+                af[i][st] = *reinterpret_cast<const bf16x8*>(&lds[buf][(wm * WM + 32 * i + c) * LDH + 8 * st + 4 * h]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int st = 0; st < 2; ++st)
+                bf[j][st] = *reinterpret_cast<const bf16x8*>(&lds[buf][(BM + wn * WN + 32 * j + c) * LDH + 8 * st + 4 * h]);
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
+        if (kc + 1 < nk) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (ksplit > 1) {
+        float* S = slab + (int64_t)ks * M * N;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WN + 32 * j + c;
+            if (n >= N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < M) S[m * N + n] = acc[i][j][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WN + 32 * j + c;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= M) continue;
+                float v = acc[i][j][r] + bv;
+                if (act == MUMPY_ACT_GELU) v = gelu_erf(v);
+                if (residual) v += residual[m * N + n];
+                Y[m * N + n] = v;
+            }
+    }
+}
+
 // split-K combine: y = act(sum_s slab[s] + bias) + residual, slices summed in fixed order (bitwise reproducible)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, const float* __restrict__ bias,
                                                             const float* residual, float* Y, int64_t MN4, int N,
@@ -384,6 +551,8 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
                   const ConvGeom* conv = nullptr) {
     if (rpb <= 0) { rpb = M; bstride = 0; }
     const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
+    const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
+    act &= 0xff;
     Plan p = make_plan(M, N, K, ws != nullptr);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
@@ -399,7 +568,17 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
                        ws, rpb, bstride, dbgmask, cg)
     static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
     static const bool use_glds = getenv("MUMPY_GEMM_GLDS") ? atoi(getenv("MUMPY_GEMM_GLDS")) != 0 : false;
-    if (p.tile == 3) {
+    if (math_bf16) {
+        const bool wide = (p.tile == 0 || p.tile == 3);
+#define MUMPY_GEMM_H(BM_, BN_, WM_, WN_, CV_)                                                                          \
+    hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, CV_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, bias,   \
+                       residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, cg)
+        if (wide && conv) MUMPY_GEMM_H(128, 128, 64, 64, true);
+        else if (wide) MUMPY_GEMM_H(128, 128, 64, 64, false);
+        else if (conv) MUMPY_GEMM_H(64, 64, 32, 32, true);
+        else MUMPY_GEMM_H(64, 64, 32, 32, false);
+#undef MUMPY_GEMM_H
+    } else if (p.tile == 3) {
         if (conv)
             hipLaunchKernelGGL((linear_kernel<128, 128, 64, 64, true, true, false>), dim3((unsigned)grid), dim3(256), 0, s, x, W,
                                bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, dbgmask, cg);
@@ -437,7 +616,8 @@ static int check_linear_args(const float* x, const float* W, const float* residu
                   "linear: pointers must be 16-byte aligned");
     MUMPY_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, MUMPY_EINVAL,
                   "linear: need K %% 32 == 0 and N %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
-    MUMPY_REQUIRE(act == MUMPY_ACT_NONE || act == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear: unknown act %d", act);
+    MUMPY_REQUIRE((act & 0xff) == MUMPY_ACT_NONE || (act & 0xff) == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear: unknown act %d", act);
+    MUMPY_REQUIRE((act & ~(0xff | MUMPY_MATH_BF16)) == 0, MUMPY_EINVAL, "linear: unknown flag bits in act 0x%x", act);
     return 0;
 }
 

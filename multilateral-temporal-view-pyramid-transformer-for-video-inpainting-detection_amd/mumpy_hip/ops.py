@@ -8,7 +8,23 @@ import torch
 from .lib import load_library
 
 ACT_NONE, ACT_GELU = 0, 1
+MATH_FP32, MATH_BF16 = 0, 0x100
+_MATH = MATH_FP32          # OR-ed into the `act` argument of every linear / conv launch
 _WS_BYTES = {}
+
+
+def set_matrix_math(mode: str) -> None:
+    """"fp32" (default): exact fp32 products on v_mfma_f32_32x32x2_f32.  "bf16": operands of every GEMM / convolution are
+    rounded to bf16 while being staged and multiplied on the bf16 MFMA with fp32 accumulation (config 3's arithmetic);
+    tensors in memory, LayerNorm / softmax / GroupNorm statistics and all other kernels stay fp32."""
+    global _MATH
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"unknown matrix math mode {mode!r}")
+    _MATH = MATH_BF16 if mode == "bf16" else MATH_FP32
+
+
+def matrix_math() -> str:
+    return "bf16" if _MATH == MATH_BF16 else "fp32"
 NEG = -1e30
 
 
@@ -81,7 +97,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
         wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
     ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None   # split-K slab (small-M shapes)
     _call("mumpy_linear_ws_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
-          _p(out), m, n, k, act, _p(ws), wsb, _stream(), work=2.0 * m * n * k)
+          _p(out), m, n, k, act | _MATH, _p(ws), wsb, _stream(), work=2.0 * m * n * k)
     return out
 
 
@@ -103,7 +119,7 @@ def linear_rows(x_view, weight, bias=None, residual=None, out=None):
         wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
     ws = torch.empty(wsb // 4, device=x_view.device, dtype=torch.float32) if wsb else None
     _call("mumpy_linear_rows_fwd", x_view.data_ptr(), rows, x_view.stride(0), _p(weight),
-          _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out), m, n, k, ACT_NONE, _p(ws), wsb, _stream(),
+          _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out), m, n, k, ACT_NONE | _MATH, _p(ws), wsb, _stream(),
           work=2.0 * m * n * k)
     return out
 
@@ -126,7 +142,7 @@ def conv2d_nhwc(x, w_krsc, bias=None, act=ACT_NONE, residual=None):
         wsb = _WS_BYTES[key] = int(_lib().mumpy_conv2d_workspace_bytes(b, h, w, cin, cout, kh, kw))
     ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None
     _call("mumpy_conv2d_nhwc_fwd", _p(x), _p(w_krsc), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out),
-          b, h, w, cin, cout, kh, kw, act, _p(ws), wsb, _stream(), work=2.0 * b * h * w * cout * kh * kw * cin)
+          b, h, w, cin, cout, kh, kw, act | _MATH, _p(ws), wsb, _stream(), work=2.0 * b * h * w * cout * kh * kw * cin)
     return out
 
 
