@@ -38,6 +38,58 @@ struct ConvGeom {
 // are fetched from a page of zeros.
 __device__ __attribute__((aligned(128))) float g_zero_page[32];
 
+// epilogue shared by the fp32 and bf16-math kernels.  D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h.
+// Addresses are a wave-uniform sub-tile base (SGPRs) plus a 32-bit element offset: row * N is a scalar multiply and the
+// lane part is computed once.  (The 64-bit m * N form costs two quarter-rate v_mul_lo_u32 and a v_mad_u64 per stored
+// row: 5-15 % of a short-K tile.)  ksplit > 1: raw partial sums -> slab[ks][M][N]; bias/act/residual happen in
+// splitk_reduce_kernel.
+template <int TM, int TN, int WM, int WN>
+__device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int c, int h,
+                                           int64_t M, int N, const float* __restrict__ bias, const float* residual,
+                                           float* Y, int act, int ksplit, int ks, float* slab) {
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm), wn_u = __builtin_amdgcn_readfirstlane(wn);
+    const int64_t mw = m0 + wm_u * WM;                                   // first row of this wave's sub-tile
+    const int64_t wbase = mw * N + n0 + wn_u * WN;
+    const int rows_left = (int)((M - mw) < (int64_t)WM ? (M - mw) : (int64_t)WM);
+    const uint32_t nb = 4u * (uint32_t)N;                                // row pitch in bytes (sub-tile extent < 4 GiB)
+    const uint32_t lane_off = 4u * h * nb + 4u * c;
+    if (ksplit > 1) {
+        char* S = reinterpret_cast<char*>(slab + (int64_t)ks * M * N + wbase);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (n0 + wn_u * WN + 32 * j + c >= N) continue;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * i + (r & 3) + 8 * (r >> 2);
+                    if (row + 4 * h < rows_left) *reinterpret_cast<float*>(S + ((uint32_t)row * nb + lane_off + 128u * j)) = acc[i][j][r];
+                }
+        }
+        return;
+    }
+    char* Yw = reinterpret_cast<char*>(Y + wbase);
+    const char* Rw = residual ? reinterpret_cast<const char*>(residual + wbase) : nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn_u * WN + 32 * j + c;
+        if (n >= N) continue;
+        const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = 32 * i + (r & 3) + 8 * (r >> 2);
+                if (row + 4 * h >= rows_left) continue;
+                const uint32_t off = (uint32_t)row * nb + lane_off + 128u * j;
+                float v = acc[i][j][r] + bv;
+                if (act == MUMPY_ACT_GELU) v = gelu_erf(v);
+                if (Rw) v += *reinterpret_cast<const float*>(Rw + off);
+                *reinterpret_cast<float*>(Yw + off) = v;
+            }
+    }
+}
+
 // PIPE: double-buffer the MFMA fragments in registers (read chunk k+1 while chunk k is in the MFMAs).  PIPE = false
 // (with GLDS) is the big-wave-tile variant: one fragment set, the DMA runs two chunks ahead, two barriers per chunk.
 template <int BM, int BN, int WM, int WN, bool CONV, bool GLDS, bool PIPE = true>
@@ -99,13 +151,18 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
         int64_t m = m0 + ld_row + RPI * i;
         if (m > M - 1) m = M - 1;
         if (CONV) {
-            const int x = (int)(m % cg.W);
-            const int y = (int)((m / cg.W) % cg.H);
+            const unsigned mu = (unsigned)m, qx = mu / (unsigned)cg.W;       // M < 2^31 (checked on the host): 32-bit division
+            const int x = (int)(mu - qx * (unsigned)cg.W);
+            const int y = (int)(qx % (unsigned)cg.H);
             ayx[i] = (y << 16) | x;
             arow[i] = X + m * cg.Cin + 4 * ld_c4;
         } else {
             ayx[i] = 0;
-            arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
+            if (rpb >= M) arow[i] = X + m * K + 4 * ld_c4;                   // dense
+            else {
+                const unsigned mu = (unsigned)m, blk = mu / (unsigned)rpb;
+                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * K + 4 * ld_c4;
+            }
         }
     }
 #pragma unroll
@@ -274,40 +331,7 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     }
     if (dbg & 16) { if (acc[0][0][0] == 12345.678f) Y[0] = 1.f; return; }
 
-    // epilogue: D[row][col]: col = lane&31, row = (r&3) + 8*(r>>2) + 4*h
-    if (ksplit > 1) {       // raw partial sums -> slab[ks][M][N]; bias/act/residual happen in splitk_reduce_kernel
-        float* S = slab + (int64_t)ks * M * N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + 32 * j + c;
-            if (n >= N) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < M) S[m * N + n] = acc[i][j][r];
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + 32 * j + c;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (act == MUMPY_ACT_GELU) v = gelu_erf(v);
-                if (residual) v += residual[m * N + n];
-                Y[m * N + n] = v;
-            }
-    }
+    store_tile<TM, TN, WM, WN>(acc, m0, n0, wm, wn, c, h, M, N, bias, residual, Y, act, ksplit, ks, slab);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -363,11 +387,16 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         int64_t m = m0 + ld_row + RPI * i;
         if (m > M - 1) m = M - 1;
         if (CONV) {
-            ayx[i] = ((int)((m / cg.W) % cg.H) << 16) | (int)(m % cg.W);
+            const unsigned mu = (unsigned)m, qx = mu / (unsigned)cg.W;       // M < 2^31 (checked on the host): 32-bit division
+            ayx[i] = ((int)(qx % (unsigned)cg.H) << 16) | (int)(mu - qx * (unsigned)cg.W);
             arow[i] = X + m * cg.Cin + 4 * ld_c4;
         } else {
             ayx[i] = 0;
-            arow[i] = X + (m / rpb) * bstride + (m % rpb) * K + 4 * ld_c4;
+            if (rpb >= M) arow[i] = X + m * K + 4 * ld_c4;                   // dense
+            else {
+                const unsigned mu = (unsigned)m, blk = mu / (unsigned)rpb;
+                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * K + 4 * ld_c4;
+            }
         }
     }
 #pragma unroll
@@ -442,39 +471,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         if (kc + 1 < nk) lstore(buf ^ 1);
         __syncthreads();
     }
-    if (ksplit > 1) {
-        float* S = slab + (int64_t)ks * M * N;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WN + 32 * j + c;
-            if (n >= N) continue;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (m < M) S[m * N + n] = acc[i][j][r];
-                }
-        }
-        return;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WN + 32 * j + c;
-        if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int64_t m = m0 + wm * WM + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= M) continue;
-                float v = acc[i][j][r] + bv;
-                if (act == MUMPY_ACT_GELU) v = gelu_erf(v);
-                if (residual) v += residual[m * N + n];
-                Y[m * N + n] = v;
-            }
-    }
+    store_tile<TM, TN, WM, WN>(acc, m0, n0, wm, wn, c, h, M, N, bias, residual, Y, act, ksplit, ks, slab);
 }
 
 // split-K combine: y = act(sum_s slab[s] + bias) + residual, slices summed in fixed order (bitwise reproducible)
@@ -614,6 +611,8 @@ static int check_linear_args(const float* x, const float* W, const float* residu
     MUMPY_REQUIRE(x && W && y, MUMPY_ENULL, "linear: null pointer");
     MUMPY_REQUIRE(aligned16(x) && aligned16(W) && aligned16(y) && aligned16(residual), MUMPY_EALIGN,
                   "linear: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(M < (1ll << 31) - 256 && (int64_t)N * 4 * 128 < (1ll << 32), MUMPY_ERANGE,
+                  "linear: M=%lld rows / N=%d columns beyond the 32-bit row index / tile byte offsets", (long long)M, N);
     MUMPY_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, MUMPY_EINVAL,
                   "linear: need K %% 32 == 0 and N %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
     MUMPY_REQUIRE((act & 0xff) == MUMPY_ACT_NONE || (act & 0xff) == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear: unknown act %d", act);

@@ -14,19 +14,24 @@
 //     accumulator->operand trick: k-slot h of step (jt,g,e) is key 32jt+8g+4h+e, which is exactly the key the
 //     lane's register 4g+e holds); V rows are loaded in that same key order, one dword per lane (128-B rows).
 //   * keys >= 49 are masked by the -1e30 columns of the pre-padded bias; queries >= 49 are never stored.
-// The unit is HBM-bound (12.25 FLOP/B): no LDS staging, ~25 KB in flight per wave, 12 waves per CU (146 VGPRs).
-// Measured on the largest launch of the B=8,T=5 forward (10,240 units, MUMPY_WA_DBG ablation, MI355X): loads only 35 us
-// (5.6 TB/s), MFMAs only 33 us, stores 10 us, launch + bias staging 10 us; the full kernel takes 72-83 us: the three
-// rounds of resident waves run in lockstep, so the phases add instead of overlapping.  At one wave per SIMD the unit is
-// strictly serial: load 2-3.3 us + MFMA/softmax 4.7 us + store 0.7 us (87 us for 10 units per SIMD).
-// Tried and measured, not kept: (1) staggered block starts: no gain; (2) cross-unit REGISTER prefetch (next window's
-// q/k/v loaded under the current MFMAs), at 2 waves/SIMD (spills) and at 1 wave/SIMD with the whole 512-register file
-// (no spills): 81-100 us, no overlap -- hipcc's waitcnt insertion treats loop-carried loads conservatively (vmcnt is one
-// in-order counter: its waits for the CURRENT unit's registers drain the prefetch behind them; predicated loads and
-// a vector-loaded mask id made it worse).  What is kept from that work: persistent blocks (bias staged once), padded
-// token slots clamped to slot 48 (branch-free loads), scalar mask-id load.  Next step: an LDS-DMA (global_load_lds)
-// ring with hand-counted vmcnt, which takes the prefetch out of the compiler's bookkeeping.
+// The unit is below the fp32 ridge (12.25 FLOP/B): no LDS staging, ~25 KB in flight per wave, 12 waves per CU (166 VGPRs).
+// Measured on the largest launch of the B=8,T=5 forward (40 frames 56x56, C=128: 10,240 units, 257 MB of q/k/v/o;
+// MUMPY_WA_DBG ablation, MI355X): 65.9 us = 30 % of the 157 TFLOP/s datasheet peak in useful 49x49 FLOPs, 46 % MFMA-busy
+// by SQ_VALU_MFMA_BUSY_CYCLES (114 MFMAs per unit incl. the 49->64 padding; profiles/r01_pmc_mfma.md).  Floors: 41 us of
+// HBM time at the 6.3 TB/s this part sustains, 38.5 us of MFMA issue at the 124 TFLOP/s a bare fp32 MFMA loop reaches.
+// Ablation: loads only 33 us, MFMAs + softmax only 46 us (80 % of the practical MFMA rate), loads + stores 41 us.
+// What moved it (79.8 -> 65.9 us):
+//   * addressing: wave-uniform bases in SGPRs + pre-multiplied 32-bit byte offsets from the token tables; the pointer form
+//     spent 66 v_mad_u64 + 130 v_mul_lo_u32 (quarter-rate) per unit, ~40 % of the MFMA time (79.8 -> 67.8 us);
+//   * one branch per unit on the mask pointer (unmasked windows run branch-free, masked ones batch their loads), no
+//     exp / max / scale work on the statically padded key slots (67.8 -> 65.9 us).
+// Tried and measured, not kept: staggered block starts, s_setprio per resident block or around the MFMA phase (no
+// change: a per-wave s_memtime trace shows the SIMD busy in some wave's compute phase ~all the time; the remaining gap
+// is the memory phase of a unit not overlapping its own wave's compute); cross-unit REGISTER prefetch at 2 waves/SIMD
+// (spills) and at 1 wave/SIMD (no overlap: hipcc's waitcnt insertion drains loop-carried prefetches); row-coalesced q/k
+// address pattern (-5 %, needs an LDS transpose).  Next step: K/V of the next unit through an LDS-DMA ring at 2 waves/SIMD.
 #include <stdlib.h>
+#include <type_traits>
 #include "common.h"
 using namespace mumpy;
 
@@ -80,30 +85,50 @@ __device__ __forceinline__ void qk_product(f32x16 (&s)[2], const f32x4 (&kf)[2][
     }
 }
 
-// add bias (+mask) rows and run the softmax over keys for the query column this lane owns (query i = 32*it + c)
-template <typename BIAS>
+// add bias (+mask) rows and run the softmax over keys for the query column this lane owns (query i = 32*it + c).
+// MASKED is a compile-time switch: the caller branches once per unit on the (wave-uniform) mask pointer, so unmasked
+// windows run branch-free and a masked window issues its 7 mask loads back to back (one wait) instead of load-wait pairs.
+template <bool MASKED, typename BIAS>
 __device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const float* mask_w, int i, int h,
-                                             float post_scale, bool skip = false) {
+                                             float post_scale) {
     constexpr float NEG = -1e30f;
-    if (skip) return;
-    float m = NEG;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (jt == 1 && g == 3) {  // keys 56..63: all padding
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s[jt][4 * g + e] = NEG;
-                continue;
-            }
-            f32x4 b = bias_at(jt, g);                                  // keys 32jt+8g+4h .. +3 of query i
-            if (mask_w) b += *reinterpret_cast<const f32x4*>(mask_w + i * 64 + 32 * jt + 8 * g + 4 * h);
+            if (jt == 1 && g == 3) continue;                             // keys 56..63: all padding
+            const f32x4 b = bias_at(jt, g);                              // keys 32jt+8g+4h .. +3 of query i
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float v = s[jt][4 * g + e] * post_scale + b[e];
-                s[jt][4 * g + e] = v;
-                m = fmaxf(m, v);
+                if (jt == 1 && g == 2 && e > 0) continue;                // keys 49..51 / 53..55: padding in both halves
+                s[jt][4 * g + e] = s[jt][4 * g + e] * post_scale + b[e];
             }
+        }
+    if (MASKED) {                                                        // (s + bias) + mask, as swin:153-157
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            f32x4 mk[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                if (!(jt == 1 && g == 3)) mk[g] = *reinterpret_cast<const f32x4*>(mask_w + i * 64 + 32 * jt + 8 * g + 4 * h);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (jt == 1 && g == 3) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (jt == 1 && g == 2 && e > 0) continue;
+                    s[jt][4 * g + e] += mk[g][e];
+                }
+            }
+        }
+    }
+    float m = NEG;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (jt == 1 && r >= 9) continue;
+            m = fmaxf(m, s[jt][r]);
         }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
@@ -111,6 +136,7 @@ __device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if (jt == 1 && r >= 9) { s[jt][r] = 0.f; continue; }        // padded keys: exp(-1e30 - m) == 0 exactly
             const float e = __expf(s[jt][r] - m);
             s[jt][r] = e;
             sum += e;
@@ -120,7 +146,10 @@ __device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[jt][r] *= inv;
+        for (int r = 0; r < 16; ++r) {
+            if (jt == 1 && r >= 9) continue;
+            s[jt][r] *= inv;
+        }
 }
 
 // the 25 (jt,g,e) MFMA steps of P V that can hold a key < 49; key of lane half h is 32jt+8g+4h+e
@@ -167,10 +196,19 @@ __device__ __forceinline__ void store_o(const f32x16& o, int it, OROW orow, int 
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int BLD = 68;   // LDS row stride of the staged bias table: 68 floats -> conflict-free ds_read_b128 across rows
 
+// byte-offset addressing: base is wave-uniform (SGPR pair), the per-lane part a 32-bit byte offset from the token tables,
+// so every access is "global_* v, v_off, s[base]" with one v_add at most -- the 64-bit token*stride products the
+// pointer form needs (2 v_mul_lo + v_mad_u64 + ... per access, all quarter-rate) cost ~40 % of the MFMA time of a unit.
+__device__ __forceinline__ const f32x4* at16(const char* base, uint32_t off) {
+    return reinterpret_cast<const f32x4*>(base + off);
+}
+
 __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
-    __shared__ int tok_tab[4][64];
+    __shared__ uint32_t tok_in[4][64];    // token * (3C*4): byte offset of the token's qkv row
+    __shared__ uint32_t tok_out[4][64];   // token * (C*4):  byte offset of the token's out row
     __shared__ __attribute__((aligned(16))) float bias_s[WT * BLD];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, h = lane >> 5;
     // a block = ONE head x 4 consecutive windows: the head's 49x49 bias table is staged once in LDS (the per-lane
     // row-strided reads of it would otherwise cost as many L1 tag cycles as the MFMAs); a (window, head) unit owns its
@@ -186,36 +224,44 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         }
     }
     __syncthreads();
-    // stagger: the resident waves of a CU would otherwise load, compute and store in lockstep (phases add up instead of
-    // overlapping); a third of the blocks start one third / two thirds of a unit late
     for (int d = 0; d < (slot % 3) * a.stagger; ++d) __builtin_amdgcn_s_sleep(127);
-    for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {
-    const bool active = true;
-    const int n = (int)(bw % a.nW);                                      // window 0 (valid memory), stores nothing
+    const int64_t L = (int64_t)a.Hs * a.W;
+    const uint32_t rsb = 12u * a.C, rob = 4u * a.C;                      // row strides in bytes
+    uint32_t* ti = tok_in[wave];
+    uint32_t* to = tok_out[wave];
+    for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {   // all scalar
+    const int n = (int)(bw % a.nW);
     const int64_t b = bw / a.nW;
     const int wy = n / a.nWx, wx = n - wy * a.nWx;
-    int* tt = tok_tab[wave];
-    tt[lane] = window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);   // padded slots -> slot 48
+    {
+        const uint32_t tok = (uint32_t)window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);   // padded slots -> slot 48
+        ti[lane] = tok * rsb;
+        to[lane] = tok * rob;
+    }
     __builtin_amdgcn_wave_barrier();
-    const int64_t L = (int64_t)a.Hs * a.W;
-    const float* base = a.qkv + b * L * 3 * a.C + head * HD;
-    const int rs = 3 * a.C;
+    const char* base = reinterpret_cast<const char*>(a.qkv + b * L * 3 * a.C + head * HD);
 
     // q/k/v go straight to registers (MFMA operand layout); branch-free
     f32x4 qf[2][4], kf[2][4];
     float vf[2][16];
     if (!(a.dbg & 1)) {
+        const char* kbase = base + 4 * a.C;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const float* row = base + (int64_t)tt[32 * t + c] * rs + 16 * h;
-            load_frag_nb(qf[t], row);
-            load_frag_nb(kf[t], row + a.C);
+            const uint32_t off = ti[32 * t + c] + 64u * h;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qf[t][i] = *at16(base, off + 16u * i);
+                kf[t][i] = *at16(kbase, off + 16u * i);
+            }
         }
-        const float* vbase = base + 2 * a.C;
-        load_v_nb(vf, [&](int j) { return vbase + (int64_t)tt[j] * rs; }, c, h);
+        const char* vbase = base + 8 * a.C;
+        for_pv_steps([&](int jt, int g, int e) {
+            vf[jt][4 * g + e] = *reinterpret_cast<const float*>(vbase + (ti[32 * jt + 8 * g + 4 * h + e] + 4u * c));
+        });
     } else {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { load_frag(qf[t], base, false); load_frag(kf[t], base, false); }
+        for (int t = 0; t < 2; ++t) { load_frag(qf[t], a.qkv, false); load_frag(kf[t], a.qkv, false); }
         for_pv_steps([&](int jt, int g, int e) { vf[jt][4 * g + e] = 1.f; });
     }
 #pragma unroll
@@ -225,39 +271,47 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
 
     const float* mask_w = nullptr;
     if (a.mask_id) {
-        const int id = a.mask_id[__builtin_amdgcn_readfirstlane((int)(bw % a.n_mask))];   // scalar load
+        const int id = a.mask_id[bw % a.n_mask];   // scalar load
         if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
     }
-    float* obase = a.out + b * L * a.C + head * HD;
+    char* obase = reinterpret_cast<char*>(a.out + b * L * a.C + head * HD);
     // the two 32-query tiles go one after the other: S needs 32 accumulator registers instead of 64
+    auto tiles = [&](auto masked) {
+        constexpr bool MASKED = decltype(masked)::value;
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-        f32x16 s[2];
+        for (int it = 0; it < 2; ++it) {
+            f32x16 s[2];
 #pragma unroll
-        for (int jt = 0; jt < 2; ++jt)
+            for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
-        if (!(a.dbg & 2)) qk_product(s, kf, qf[it]);
-        else { s[0][0] = kf[0][0][0] + qf[it][0][0]; s[1][3] = kf[1][1][1] * qf[it][2][1]; }
-        const int qi = 32 * it + c;
-        const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];        // padded queries re-read row 48
-        bias_softmax(s, [&](int jt, int g) {
-            f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
-            if (jt == 1 && g == 2) {                                               // keys 48..55: only key 48 is real
-                if (h) bv = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
-                else { bv.y = -1e30f; bv.z = -1e30f; bv.w = -1e30f; }
-            }
-            return bv;
-        }, mask_w, qi, h, 1.0f, (a.dbg & 2) != 0);
-        f32x16 o;
+                for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
+            if (!(a.dbg & 2)) qk_product(s, kf, qf[it]);
+            else { s[0][0] = kf[0][0][0] + qf[it][0][0]; s[1][3] = kf[1][1][1] * qf[it][2][1]; }
+            const int qi = 32 * it + c;
+            const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];    // padded queries re-read row 48
+            if (!(a.dbg & 2))
+                bias_softmax<MASKED>(s, [&](int jt, int g) {
+                    f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
+                    if (jt == 1 && g == 2 && h) bv.x = -1e30f;                     // key 52 is padding (key 48 is real)
+                    return bv;
+                }, mask_w, qi, h, 1.0f);
+            f32x16 o;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] = 0.f;
-        if (!(a.dbg & 2)) pv_product(o, s, vf);
-        else { o[0] = s[0][0] + vf[0][0]; o[5] = s[1][2] * vf[1][8]; }
-        if (active && !(a.dbg & 4)) store_o(o, it, [&](int i) { return obase + (int64_t)tt[i] * a.C; }, c, h);
-        else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1.f;
-    }
-    __builtin_amdgcn_wave_barrier();   // the token table is rewritten by the next unit
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            if (!(a.dbg & 2)) pv_product(o, s, vf);
+            else { o[0] = s[0][0] + vf[0][0]; o[5] = s[1][2] * vf[1][8]; }
+            if (!(a.dbg & 4)) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
+                    const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (i < WT) *reinterpret_cast<float*>(obase + (to[i] + 4u * c)) = o[r];
+                }
+            } else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1;
+        }
+    };
+    if (mask_w) tiles(std::true_type{}); else tiles(std::false_type{});
+    __builtin_amdgcn_wave_barrier();   // the token tables are rewritten by the next unit
     }
 }
 
@@ -308,12 +362,9 @@ __global__ __launch_bounds__(256, 2) void win_attn_cross_kernel(CrossArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
             qk_product(s, kf, qf[it]);
-            bias_softmax(s, [&](int jt, int g) {                               // no bias: only the 49->64 key padding
+            bias_softmax<false>(s, [&](int jt, int g) {                        // no bias: only the 49->64 key padding
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (jt == 1 && g == 2) {
-                    if (h) bv = f32x4{-1e30f, -1e30f, -1e30f, -1e30f};
-                    else { bv.y = -1e30f; bv.z = -1e30f; bv.w = -1e30f; }
-                }
+                if (jt == 1 && g == 2 && h) bv.x = -1e30f;                      // key 52 is padding (key 48 is real)
                 return bv;
             }, nullptr, 32 * it + c, h, a.scale);                               // scale on the product (deform:364)
             pv_product(o[it], s, vf);
