@@ -173,10 +173,11 @@ int mumpy_gn_apply_resample_nhwc_fwd(const float* x, const float* partial, int n
                                      float* out, int out_ctot, int out_coff, int B, int H, int W, int C,
                                      void* stream);
 
-/* final_out (decoder.py:95,223): Conv2d(32 -> 1, 3x3, pad 1) on x (B,H,W,32) NHWC, w_krsc (1,3,3,32), bias (1);
- * logits (B,1,H,W) fp32; mask (B,1,H,W) uint8 = sigmoid(logit) > thr, or NULL (the eval tail of test.py:100-108 fused). */
+/* final_out (decoder.py:95,223; BaselineDecoder decoder.py:275): Conv2d(C -> 1, 3x3, pad 1) on x (B,H,W,C) NHWC with
+ * C a multiple of 32 (32 for Decoder, 256 for BaselineDecoder), w_krsc (1,3,3,C), bias (1); logits (B,1,H,W) fp32;
+ * mask (B,1,H,W) uint8 = sigmoid(logit) > thr, or NULL (the eval tail of test.py:100-108 fused). */
 int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias, float* logits, uint8_t* mask, int B,
-                         int H, int W, float thr, void* stream);
+                         int H, int W, int C, float thr, void* stream);
 
 /* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
 int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);

@@ -207,18 +207,57 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     }
 }
 
+// same conv for C = 32*k input channels (BaselineDecoder.final_out is Conv2d(256 -> 1), decoder:275): the 8 lanes of a
+// pixel walk the channel blocks, weights come from L1 instead of registers.
+__global__ __launch_bounds__(256) void final_conv_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ logits,
+                                                              uint8_t* __restrict__ mask, int H, int W, int C, int64_t npix,
+                                                              float thr) {
+    const int sub = threadIdx.x & 7;
+    const float b0 = bias[0];
+    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 3) {
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        float acc = 0.f;
+        for (int cb = 0; cb < C; cb += 32) {
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if ((unsigned)(yy + dy) >= (unsigned)H || (unsigned)(xx + dx) >= (unsigned)W) continue;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(x + (pix + dy * W + dx) * C + cb + 4 * sub);
+                    const f32x4 k = *reinterpret_cast<const f32x4*>(w + ((dy + 1) * 3 + dx + 1) * C + cb + 4 * sub);
+                    acc += (v.x * k.x + v.y * k.y) + (v.z * k.z + v.w * k.w);
+                }
+        }
+        acc += __shfl_xor(acc, 1);
+        acc += __shfl_xor(acc, 2);
+        acc += __shfl_xor(acc, 4);
+        if (sub == 0) {
+            const float z = acc + b0;
+            logits[pix] = z;
+            if (mask) mask[pix] = (1.0f / (1.0f + __expf(-z)) > thr) ? 1 : 0;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias, float* logits, uint8_t* mask,
-                                    int B, int H, int W, float thr, void* stream) {
+                                    int B, int H, int W, int C, float thr, void* stream) {
     MUMPY_REQUIRE(x && w_krsc && bias && logits, MUMPY_ENULL, "final_conv: null pointer");
     MUMPY_REQUIRE(aligned16(x) && aligned16(w_krsc), MUMPY_EALIGN, "final_conv: x and w must be 16-byte aligned");
-    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0, MUMPY_EINVAL, "final_conv: bad shape");
+    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 32 == 0, MUMPY_EINVAL,
+                  "final_conv: bad shape (C=%d must be a multiple of 32)", C);
     const int64_t npix = (int64_t)B * H * W;
     int64_t grid = (npix * 8 + 255) / 256;
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, bias, logits,
-                       mask, H, W, npix, thr);
+    if (C == 32)
+        hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, bias, logits,
+                           mask, H, W, npix, thr);
+    else
+        hipLaunchKernelGGL(final_conv_wide_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, bias,
+                           logits, mask, H, W, C, npix, thr);
     MUMPY_CHECK_LAUNCH("final_conv");
     return 0;
 }

@@ -251,3 +251,45 @@ class Decoder(nn.Module):
         x_feats = self._features(x, view_x, ffinfo)
         logits, mask = ops.final_conv(x_feats, self._final_weight(), self.final_out.bias, with_mask=True, thr=thr)
         return logits, mask, x_feats
+
+
+class BaselineDecoder(nn.Module):
+    """Single-scale decoder of config 1 (decoder.py:228-284): five x (conv3x3 -> GroupNorm(32) -> ReLU -> bilinear x2,
+    align_corners=True) and a 3x3 conv to the logits.  Same constructor / state_dict as the reference; note the reference
+    builds every GroupNorm with `features[1]` channels (decoder.py:236-265), which is kept.  With `BaselineEncoder` the
+    caller must pass `in_channels=1024` (the 2304 default only fits the three-view encoder).
+    NHWC throughout: implicit-GEMM convs, GroupNorm + ReLU + upsample as one streaming kernel per block."""
+
+    def __init__(self, in_channels=2304, out_channels=1, features=[256, 256, 256, 256, 256]):
+        super().__init__()
+        cin = in_channels
+        for i in range(5):
+            setattr(self, f"decoder_{i + 1}", nn.Sequential(
+                nn.Conv2d(cin, features[i], 3, padding=1), nn.GroupNorm(32, features[1]), nn.ReLU(inplace=True),
+                nn.Upsample(scale_factor=2, mode="bilinear", align_corners=True)))
+            cin = features[i]
+        self.final_out = nn.Conv2d(features[-1], out_channels, 3, padding=1)
+        self._derived = {}
+
+    def _cached(self, key, sources, fn):
+        d = self._derived.get(key)
+        if d is None:
+            d = self._derived[key] = Derived()
+        return d.get(sources, fn)
+
+    def _block(self, seq, x):
+        conv, gn = seq[0], seq[1]
+        w = self._cached(("w", id(conv)), (conv.weight,), lambda: conv.weight.permute(0, 2, 3, 1).contiguous())
+        y, partial, nsplit = ops.gn_stats(ops.conv2d_nhwc(x, w, conv.bias), gn.num_groups)
+        return ops.gn_apply_resample(y, (partial, nsplit, gn.weight, gn.bias, gn.num_groups, gn.eps), act=ops.ACT_RELU,
+                                     scale=2, align_corners=True)
+
+    def forward(self, x):
+        """x (B,in_channels,7,7) -> logits (B,out_channels=1,224,224)."""
+        if self.final_out.out_channels != 1:
+            raise NotImplementedError("BaselineDecoder: the HIP final conv emits one logit channel (the reference default)")
+        x = x.contiguous(memory_format=torch.channels_last)
+        for i in range(5):
+            x = self._block(getattr(self, f"decoder_{i + 1}"), x)
+        wf = self._cached(("wf",), (self.final_out.weight,), lambda: self.final_out.weight.permute(0, 2, 3, 1).contiguous())
+        return ops.final_conv(x, wf, self.final_out.bias)

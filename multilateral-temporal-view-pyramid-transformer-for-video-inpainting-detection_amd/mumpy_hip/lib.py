@@ -24,7 +24,7 @@ SIGNATURES = {
                                          c_i, c_i, c_i, c_i, c_f],
     "mumpy_conv2d_nhwc_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_conv2d_workspace_bytes": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
-    "mumpy_final_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_final_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_window_attention_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_deform_offsets_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_sample_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],

@@ -147,14 +147,14 @@ def conv2d_nhwc(x, w_krsc, bias=None, act=ACT_NONE, residual=None):
 
 
 def final_conv(x, w_krsc, bias, with_mask=False, thr=0.5):
-    """x logical (B,32,H,W) NHWC -> logits (B,1,H,W) [, uint8 mask (B,1,H,W)]."""
+    """x logical (B,C,H,W) NHWC, C a multiple of 32 -> logits (B,1,H,W) [, uint8 mask (B,1,H,W)]."""
     x = _nhwc(x, "x")
     b, c, h, w = x.shape
-    if c != 32 or tuple(w_krsc.shape) != (1, 3, 3, 32):
-        raise RuntimeError("final_conv is built for Conv2d(32, 1, 3, padding=1)")
+    if c % 32 or tuple(w_krsc.shape) != (1, 3, 3, c):
+        raise RuntimeError(f"final_conv is built for Conv2d(32k, 1, 3, padding=1); got C={c}, weight {tuple(w_krsc.shape)}")
     logits = torch.empty(b, 1, h, w, device=x.device, dtype=torch.float32)
     mask = torch.empty(b, 1, h, w, device=x.device, dtype=torch.uint8) if with_mask else None
-    _call("mumpy_final_conv_fwd", _p(x), _p(_chk(w_krsc, "weight")), _p(_chk(bias, "bias")), _p(logits), _p(mask), b, h, w, thr,
+    _call("mumpy_final_conv_fwd", _p(x), _p(_chk(w_krsc, "weight")), _p(_chk(bias, "bias")), _p(logits), _p(mask), b, h, w, c, thr,
           _stream(), work=4.0 * (x.numel() + logits.numel()))
     return (logits, mask) if with_mask else logits
 

@@ -411,6 +411,16 @@ def baseline_encoder_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
     return y.reshape(b, 7, 7, -1).permute(0, 3, 1, 2).contiguous()
 
 
+def baseline_decoder_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
+    """BaselineDecoder.forward (decoder.py:277-284): 5 x [conv3x3 -> GroupNorm(32) -> ReLU -> bilinear x2 with
+    align_corners=True] (decoder.py:233-271) then final_out conv3x3 (decoder.py:273).  sd: un-prefixed decoder state_dict."""
+    for i in range(1, 6):
+        x = F.conv2d(x, sd[f"decoder_{i}.0.weight"], sd[f"decoder_{i}.0.bias"], padding=1)
+        x = F.relu(F.group_norm(x, 32, sd[f"decoder_{i}.1.weight"], sd[f"decoder_{i}.1.bias"], eps=1e-5))
+        x = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=True)
+    return F.conv2d(x, sd["final_out.weight"], sd["final_out.bias"], padding=1)
+
+
 # ----------------------------------------------------------------------------------------------
 # SURVEY 8f-1: eval-harness tail (test.py:100-111) and F1/IoU (measure.py:57-62, 86-89)
 # ----------------------------------------------------------------------------------------------

@@ -267,6 +267,15 @@ def main():
     y = benc(inp(full, "base_b1t3/x", 1237, 1, 3, 3, 224, 224))
     full["base_b1t3/y"] = y.numpy().astype(f32)
     print("baseline", tuple(y.shape), float(y.abs().max()))
+    # config 1 decoder: BaselineDecoder(in_channels=1024) on the baseline encoder's output (decoder.py:228-284)
+    from models.decoder.decoder import BaselineDecoder
+    bdec = BaselineDecoder(in_channels=1024).eval()
+    with open(os.path.join(out, "state_dict_baseline_decoder.json"), "w") as f:
+        json.dump(sd_manifest(bdec), f)
+    fill_module_(bdec)
+    z = bdec(y)
+    full["base_b1t3/logits"] = z.numpy().astype(f32)
+    print("baseline decoder", tuple(z.shape), float(z.abs().max()))
     np.savez_compressed(os.path.join(out, "full_model.npz"), **{k: np.ascontiguousarray(v) for k, v in full.items()})
 
     for fn in sorted(os.listdir(out)):

@@ -427,6 +427,28 @@ def test_baseline_encoder(full_golden):
     assert rel_err(y.cpu(), full_golden["base_b1t3/y"]) < TOL
 
 
+def test_baseline_decoder(full_golden):
+    """config 1 tail (decoder.py:228-284): golden logits of the reference BaselineDecoder(in_channels=1024)."""
+    from models.decoder.decoder import BaselineDecoder
+    dec = _load_filled(BaselineDecoder(in_channels=1024), DEV)
+    with torch.no_grad():
+        z = dec(torch.from_numpy(full_golden["base_b1t3/y"]).to(DEV))
+    assert z.shape == (1, 1, 224, 224)
+    assert rel_err(z.cpu(), full_golden["base_b1t3/logits"]) < TOL
+
+
+def test_baseline_pipeline_b3_vs_oracle():
+    """BaselineEncoder -> BaselineDecoder at B=3 (odd batch) against the oracle on the same seeded input."""
+    from models.decoder.decoder import BaselineDecoder
+    from models.encoder.encoder import BaselineEncoder
+    enc, dec = _load_filled(BaselineEncoder(), DEV), _load_filled(BaselineDecoder(in_channels=1024), DEV)
+    x = seeded_randn(77, 3, 3, 3, 224, 224)
+    with torch.no_grad():
+        z = dec(enc(x.to(DEV)))
+        ref = O.baseline_decoder_forward(cpu_sd(dec), O.baseline_encoder_forward(cpu_sd(enc), x))
+    assert rel_err(z.cpu(), ref) < TOL
+
+
 def test_predict_mask_fused_tail(model_t3):
     """Decoder.predict_mask: final conv + sigmoid + threshold in one kernel == forward() followed by test.py:100-108."""
     enc, dec = model_t3

@@ -22,6 +22,8 @@ def manifest(m):
     ("state_dict_decoder_t5.json",
      lambda: __import__("models.decoder.decoder", fromlist=["Decoder"]).Decoder(input_token_temporal_dims=[1, 1, 5])),
     ("state_dict_baseline_encoder.json", lambda: __import__("models.encoder.encoder", fromlist=["BaselineEncoder"]).BaselineEncoder()),
+    ("state_dict_baseline_decoder.json",
+     lambda: __import__("models.decoder.decoder", fromlist=["BaselineDecoder"]).BaselineDecoder(in_channels=1024)),
 ])
 def test_state_dict_contract(fname, ctor):
     """Same keys, shapes, dtypes AND order as the reference model (test.py:60-61 loads strictly)."""

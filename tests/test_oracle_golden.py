@@ -252,3 +252,12 @@ def test_baseline_encoder(full_golden):
     with torch.no_grad():
         y = O.baseline_encoder_forward(sd, golden_input(full_golden, "base_b1t3/x"))
     assert rel_err(y, full_golden["base_b1t3/y"]) < FULL_TOL
+
+
+def test_baseline_decoder(full_golden):
+    """config 1 tail: BaselineDecoder(in_channels=1024) on the golden encoder output (decoder.py:228-284)."""
+    sd = _filled("state_dict_baseline_decoder.json")
+    with torch.no_grad():
+        z = O.baseline_decoder_forward(sd, torch.from_numpy(full_golden["base_b1t3/y"]))
+    assert z.shape == (1, 1, 224, 224)
+    assert rel_err(z, full_golden["base_b1t3/logits"]) < FULL_TOL
