@@ -24,6 +24,32 @@ def generate_filter(start, end, size):
     return ((s >= start) & (s <= end)).astype(np.float64)
 
 
+def generate_fine_grained_filter(start, end, size):
+    m = np.zeros((size, size), dtype=np.float64)
+    if 0 <= start < size and 0 <= end < size:
+        m[int(start), int(end)] = 1.0
+    return m
+
+
+class Filter(nn.Module):
+    """Band mask holder with the reference's constructor (dct.py:11-39).  In the default configuration FAF uses
+    (use_learnable=False, norm=False) it has no parameters and `forward` is `x * base`; FAF's HIP kernel applies the three
+    masks inside the DCT pass from the band limits, so this module is API surface (attribute `filters`), not the hot path.
+    The learnable / norm variants are never built by the reference's model code and are not provided."""
+
+    def __init__(self, size, band_start, band_end, use_learnable=False, norm=False, fine_grain=False):
+        super().__init__()
+        if use_learnable or norm:
+            raise NotImplementedError("Filter: only the fixed band mask FAF uses (use_learnable=False, norm=False)")
+        self.use_learnable, self.norm = False, False
+        self.band = (band_start, band_end)
+        gen = generate_fine_grained_filter if fine_grain else generate_filter
+        self.base = torch.tensor(gen(band_start, band_end, size))        # plain attribute, fp64 like the reference
+
+    def forward(self, x):
+        return x * self.base.to(x.device)
+
+
 class FAF(nn.Module):
     def __init__(self, size=224):
         super().__init__()
@@ -31,6 +57,8 @@ class FAF(nn.Module):
             raise NotImplementedError("the HIP DCT kernel is tiled for 224 = 7*32")
         self.fn = 3
         self.size = size
+        self.filters = nn.ModuleList([Filter(size, 0, size // 2.82), Filter(size, size // 2.82, size // 2),
+                                      Filter(size, size * 1, size * 2)])                    # dct.py:66-69; no state
         d = torch.tensor(DCT_mat(size)).float()            # fp64 build, then .float() (dct.py:60)
         self._host = (d.contiguous(), d.t().contiguous())
         self._dev = {}
