@@ -193,12 +193,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU path)")
+    # MUMPY_BENCH_BACKEND=gloo rehearses the N>1 launch path on a box with fewer GPUs than ranks (ranks share devices);
+    # the driver's runs use the default: RCCL, one GPU per rank.
+    backend = os.environ.get("MUMPY_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # host threads: N ranks build their weights concurrently on one node; keep each within its share of the cores
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     from mumpy_hip import distributed as D
-    D.init_process_group("nccl", dev)                        # RCCL over xGMI (no-op at world 1)
+    D.init_process_group(backend, dev)                       # "nccl" = RCCL over xGMI (no-op at world 1)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
 
     from models.decoder.decoder import Decoder
@@ -250,7 +255,7 @@ def main():
     # per-image F1/IoU on device (measure.py:57-62,86-89) + the ONE collective of the path: all-reduce of the metric vector
     metric = D.all_reduce_metric(D.eval_metric_vector(mask, gt))
     barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev if backend == "nccl" else None)
 
     if rank == 0:
         log(f"timed: {1e3 * dt / args.steps:.2f} ms/step; profiling kernels")

@@ -49,6 +49,10 @@ def eval_metric_vector(pred_mask: torch.Tensor, gt_mask: torch.Tensor) -> torch.
 def all_reduce_metric(vec: torch.Tensor) -> torch.Tensor:
     """The single collective of the inference path (24 bytes: latency-bound, topology-irrelevant)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if vec.is_cuda and dist.get_backend() == "gloo":     # CPU rehearsal backend: reduce on the host
+            host = vec.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            return vec.copy_(host)
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return vec
 
