@@ -133,3 +133,38 @@ def test_eval_metric_formulas():
     precision = 4 / (8 + 1e-6)
     assert abs(float(f1) - 2 * precision * recall / (precision + recall + 1e-6)) < 1e-12
     assert abs(float(iou) - (4 + 1e-5) / (12 + 1e-5)) < 1e-12
+
+
+def test_check_parallel_strips_dataparallel_prefix(tmp_path):
+    """utils/utils.py:156-176: 'module.'-prefixed checkpoints (trained under nn.DataParallel) load strictly."""
+    from models.decoder.decoder import BaselineDecoder
+    from mumpy_hip import checkpoint as C
+    dec = BaselineDecoder(in_channels=64, features=[32] * 5)
+    enc = torch.nn.Linear(4, 4)
+    wrapped_e = {"module." + k: v for k, v in enc.state_dict().items()}
+    wrapped_d = {"module." + k: v for k, v in dec.state_dict().items()}
+    e, d = C.check_parallel(wrapped_e, wrapped_d)
+    assert list(e) == list(enc.state_dict()) and list(d) == list(dec.state_dict())
+    e2, d2 = C.check_parallel(enc.state_dict(), dec.state_dict())          # already clean: untouched
+    assert list(e2) == list(enc.state_dict()) and list(d2) == list(dec.state_dict())
+    # file round trip in the reference's naming (encoder_{epoch}.pt / decoder_{epoch}.pt), DataParallel-style keys on disk
+    torch.save(wrapped_e, tmp_path / "encoder_7.pt")
+    torch.save(wrapped_d, tmp_path / "decoder_7.pt")
+    e3, d3, args = C.load_checkpoint(str(tmp_path), epoch=7)
+    assert args is None
+    enc.load_state_dict(e3, strict=True)
+    dec.load_state_dict(d3, strict=True)
+    C.save_checkpoint(str(tmp_path / "out"), enc, dec, epoch=None, args={"length_clip": 3, "batch_size": 8})
+    e4, d4, args = C.load_checkpoint(str(tmp_path / "out"))
+    assert args == {"length_clip": 3, "batch_size": 8}
+    assert all(torch.equal(d4[k], v) for k, v in dec.state_dict().items())
+
+
+def test_clip_frame_indices_clamp():
+    """universaldataloader.py:41-46: one clip per frame, centred, clamped at both ends."""
+    from mumpy_hip.checkpoint import clip_frame_indices
+    assert clip_frame_indices(4, 3) == [[0, 0, 1], [0, 1, 2], [1, 2, 3], [2, 3, 3]]
+    c5 = clip_frame_indices(3, 5)
+    assert c5 == [[0, 0, 0, 1, 2], [0, 0, 1, 2, 2], [0, 1, 2, 2, 2]]
+    assert all(len(c) == 5 for c in clip_frame_indices(10, 4))              # even length_clip -> 2k+1 = 5 frames
+    assert clip_frame_indices(0, 3) == []
