@@ -192,6 +192,26 @@ int mumpy_normalize_u8_fwd(const uint8_t* frames, float* out, int64_t nframes, i
  *      consumed by the next view (mTVE:275-276).  out may alias a or b. */
 int mumpy_add_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);
 
+/* ---- training tail -------------------------------------------------------------------
+ * mask loss = softIoULoss + WeightedFocalLoss exactly as train.py:107-113 calls utils/loss.py:6-55 on logits (B,P) and
+ * 0/1 targets (B,P): per-sample soft IoU with guard `eps` (the reference call site passes `recall`=False into the `e`
+ * slot, loss.py:49, so eps = 0 there), focal with alpha=[1,1], gamma=2 averaged over all B*P elements.
+ * loss3[0..2] = {(iou + focal) * loss_scale, iou, focal}; dlogits (B,P) = d(loss3[0])/dlogits, or NULL for loss only.
+ * loss_scale = 1 / accumulation_steps (train.py:115).  Deterministic (fixed-order reductions, no atomics).
+ * workspace: device scratch of mumpy_mask_loss_workspace_bytes(B,P) bytes, caller-owned. */
+int64_t mumpy_mask_loss_workspace_bytes(int B, int64_t P);
+int mumpy_mask_loss_fwd_bwd(const float* logits, const float* target, float* dlogits, float* loss3, void* workspace,
+                            int64_t workspace_bytes, int B, int64_t P, float eps, float loss_scale, void* stream);
+
+/* fused AdamW step over a FLAT buffer of n parameters (torch.optim.AdamW single-tensor semantics, utils/utils.py:258):
+ *   p *= 1 - lr*wd;  m += (1-b1)(g - m);  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * with g = grad * grad_scale (e.g. 1/world_size after a sum all-reduce).  step t >= 1 is the count INCLUDING this
+ * update.  In place on param / exp_avg / exp_avg_sq.  Hyper-parameters are doubles (the Python floats torch receives):
+ * each derived factor is rounded to fp32 once, as torch does, so the update matches torch.optim.AdamW to round-off. */
+int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                     double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

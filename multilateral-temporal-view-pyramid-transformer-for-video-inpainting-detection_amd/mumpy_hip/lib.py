@@ -11,6 +11,7 @@ c_f = ctypes.c_void_p      # device pointers travel as void*
 c_i = ctypes.c_int
 c_l = ctypes.c_int64
 c_fl = ctypes.c_float
+c_d = ctypes.c_double
 
 # name -> argtypes; mirrors include/mumpy_hip.h one to one (tests/test_abi.py checks the header against this)
 SIGNATURES = {
@@ -37,6 +38,9 @@ SIGNATURES = {
     "mumpy_sigmoid_threshold_fwd": [c_f, c_f, c_l, c_fl, c_f],
     "mumpy_add_fwd": [c_f, c_f, c_f, c_l, c_f],
     "mumpy_normalize_u8_fwd": [c_f, c_f, c_l, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f],
+    "mumpy_mask_loss_workspace_bytes": [c_i, c_l],
+    "mumpy_mask_loss_fwd_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_fl, c_fl, c_f],
+    "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }
 ABI_VERSION = 1
 

@@ -364,3 +364,32 @@ def normalize_u8(frames, mean=EVAL_MEAN, std=EVAL_STD):
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     _call("mumpy_normalize_u8_fwd", _p(frames), _p(out), n, h, w, m3, s3, _stream(), work=float(frames.numel() + 4 * out.numel()))
     return out
+
+
+# ---------------------------------------------------------------------------------------------- training tail (8f-2)
+def mask_loss(logits, target, need_grad=True, eps=0.0, loss_scale=1.0):
+    """softIoULoss + WeightedFocalLoss as train.py:107-113 calls them (utils/loss.py:6-55).  logits (B,...) and 0/1 target of the
+    same number of elements per sample -> (loss3 = [total*loss_scale, iou, focal] device tensor, dlogits or None)."""
+    logits = _chk(logits, "logits")
+    b = logits.shape[0]
+    p = logits.numel() // b
+    target = _chk(target.to(torch.float32).reshape(b, p), "target")
+    loss3 = torch.empty(3, device=logits.device, dtype=torch.float32)
+    dz = torch.empty_like(logits) if need_grad else None
+    wsb = int(_lib().mumpy_mask_loss_workspace_bytes(b, p))
+    ws = torch.empty(wsb // 4, device=logits.device, dtype=torch.float32)
+    _call("mumpy_mask_loss_fwd_bwd", _p(logits), _p(target), _p(dz), _p(loss3), _p(ws), wsb, b, p, eps, loss_scale, _stream(),
+          work=4.0 * logits.numel() * (5 if need_grad else 2))
+    return loss3, dz
+
+
+def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    """In-place fused AdamW over flat fp32 buffers (torch.optim.AdamW defaults; step counts from 1)."""
+    n = param.numel()
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _chk(t, name)
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError(f"adamw_step: {name} must be a contiguous buffer of {n} elements (in-place update)")
+    _call("mumpy_adamw_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, betas[0], betas[1], eps, weight_decay,
+          int(step), grad_scale, _stream(), work=28.0 * n)
+    return param

@@ -1,0 +1,106 @@
+"""Training tail of config 5: parameter groups, fused AdamW on flat buffers, the polynomial LR schedule and
+the bucketed gradient all-reduce.  The model backward itself is not part of this round (forward kernels only), so these
+pieces are exercised on their own: loss + gradient wrt the logits, optimizer update, schedule, collective.
+
+Reference behaviour reproduced:
+  * three optimizers: encoder parameters whose name contains "cva" / the other encoder parameters / the decoder
+    (train.py:198-213), each `torch.optim.AdamW(lr, weight_decay)` with torch defaults otherwise (utils/utils.py:258);
+  * `PolynomialLR` (utils/optimizer/scheduler.py:6-43) with power 0.9, min_lr 1e-5, step_size 1, no warm-up
+    (train.py:226-262), stepped once per optimizer step;
+  * gradient accumulation: loss / accumulation_steps (train.py:115), update every accumulation_steps iterations;
+  * nn.DataParallel's gradient (grad of the mean loss over the global batch) == the mean over ranks of per-rank gradients
+    for equal shards: one sum all-reduce of the flat gradient buffer in buckets + the 1/world factor folded into AdamW.
+"""
+from typing import Dict, Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops
+
+
+def split_param_groups(encoder: torch.nn.Module, decoder: torch.nn.Module) -> Dict[str, List[torch.nn.Parameter]]:
+    """train.py:198-213: {"cva": encoder params with "cva" in the name, "enc": the other encoder params, "dec": decoder}."""
+    groups = {"cva": [], "enc": [], "dec": [p for p in decoder.parameters() if p.requires_grad]}
+    for name, p in encoder.named_parameters():
+        if p.requires_grad:
+            groups["cva" if "cva" in name else "enc"].append(p)
+    return groups
+
+
+def polynomial_lr(base_lr: float, current_lr: float, it: int, iter_max: int, power: float = 0.9, min_lr: float = 1e-5,
+                  iter_warmup: int = 0, step_size: int = 1) -> float:
+    """Learning rate after the `it`-th scheduler step (scheduler.py:24-41, `last_epoch` = it).  Faithful to its guards:
+    the rate is left unchanged at it == 0, when it is not a multiple of step_size, and past iter_max."""
+    iter_max, iter_warmup = int(iter_max), int(iter_warmup)
+    if it == 0 or it % step_size != 0 or it > iter_max:
+        return current_lr
+    if it < iter_warmup:
+        coef = it / iter_warmup * (1 - iter_warmup / iter_max) ** power
+    else:
+        coef = (1 - it / iter_max) ** power
+    return (base_lr - min_lr) * coef + min_lr
+
+
+class FlatAdamW:
+    """One parameter group of the reference's AdamW, held as flat fp32 buffers: the parameters are re-pointed at views
+    of `self.param`, their `.grad` at views of `self.grad`, so a step is ONE kernel over the group and the gradient
+    all-reduce runs over one contiguous buffer.  State layout (exp_avg, exp_avg_sq, step) matches torch.optim.AdamW."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float, weight_decay: float = 1e-2, betas=(0.9, 0.999),
+                 eps: float = 1e-8):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("FlatAdamW: empty parameter group")
+        dev = self.params[0].device      # buffers can be built anywhere; step() needs the GPU (the HIP kernel has no CPU twin)
+        sizes = [(p.numel() + 3) // 4 * 4 for p in self.params]          # 16-B aligned slots
+        self.offsets = [0]
+        for s in sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        n = self.offsets[-1]
+        self.param = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
+        self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
+        for p, o in zip(self.params, self.offsets):
+            view = self.param[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self.base_lr = self.lr = lr
+        self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
+        self.steps = 0            # optimizer steps taken
+        self.sched_it = 0         # scheduler steps taken (PolynomialLR.last_epoch)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def all_reduce_grads(self, bucket_bytes: int = 64 << 20):
+        """Sum all-reduce of the flat gradient in buckets (RCCL ring over xGMI: per-link bound, so a few tens of MB per
+        call keeps the ring busy without delaying the first bucket); returns the factor AdamW must apply (1/world)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return 1.0
+        per = max(1, bucket_bytes // 4)
+        for o in range(0, self.grad.numel(), per):
+            dist.all_reduce(self.grad[o:o + per], op=dist.ReduceOp.SUM)
+        return 1.0 / dist.get_world_size()
+
+    def step(self, grad_scale: float = 1.0):
+        self.steps += 1
+        ops.adamw_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.steps, self.lr, self.betas, self.eps,
+                       self.weight_decay, grad_scale)
+
+    def scheduler_step(self, iter_max: int, power: float = 0.9, min_lr: float = 1e-5):
+        self.sched_it += 1
+        self.lr = polynomial_lr(self.base_lr, self.lr, self.sched_it, iter_max, power, min_lr)
+        return self.lr
+
+
+def build_optimizers(encoder, decoder, lr_cnn: float, lr: float, lr_cva: Optional[float] = None, weight_decay: float = 1e-2,
+                     weight_decay_cnn: float = 1e-2) -> Dict[str, FlatAdamW]:
+    """train.py:211-213: cva / encoder / decoder optimizers (cva omitted when the encoder has no such parameters)."""
+    g = split_param_groups(encoder, decoder)
+    opts = {"enc": FlatAdamW(g["enc"], lr_cnn, weight_decay_cnn), "dec": FlatAdamW(g["dec"], lr, weight_decay)}
+    if g["cva"]:
+        opts["cva"] = FlatAdamW(g["cva"], lr_cva if lr_cva is not None else lr_cnn, weight_decay)
+    return opts

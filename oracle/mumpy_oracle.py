@@ -447,3 +447,32 @@ def metric_vector(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     reported metrics are the means (measure.py:128-130)."""
     f1, iou = f1_iou_per_clip(pred, gt)
     return torch.stack([f1.sum(), iou.sum(), torch.tensor(float(pred.shape[0]), dtype=torch.float64)])
+
+
+# ----------------------------------------------------------------------------------------------
+# SURVEY 8f-2: training tail — mask loss (utils/loss.py:6-55 as called at train.py:107-113), PolynomialLR
+# (utils/optimizer/scheduler.py:24-41).  AdamW's checker is torch.optim.AdamW itself (utils/utils.py:258).
+# ----------------------------------------------------------------------------------------------
+def mask_loss(logits: torch.Tensor, target: torch.Tensor, eps: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """-> (iou + focal, iou, focal); differentiable in `logits`.  logits (B,...), target 0/1 with the same per-sample size.
+    softIoU: loss.py:27-42 with e = eps (the call site loss.py:49 passes recall=False into `e`, i.e. 0) averaged over the
+    batch (loss.py:54, train.py:108); focal: loss.py:15-24 with alpha=[1,1] (loss.py:12), gamma=2, mean over all elements."""
+    b = logits.shape[0]
+    z = logits.reshape(b, -1)
+    t = target.reshape(b, -1).to(z.dtype)
+    p = torch.sigmoid(z)
+    iou = (1 - (p * t).sum(1) / ((p + t - p * t).sum(1) + eps)).mean()
+    bce = F.binary_cross_entropy_with_logits(z, t, reduction="none")
+    focal = ((1 - torch.exp(-bce)) ** 2 * bce).mean()
+    return iou + focal, iou, focal
+
+
+def polynomial_lr_sequence(base_lr: float, iter_max: int, steps: int, power: float = 0.9, min_lr: float = 1e-5) -> List[float]:
+    """Learning rates [before any step, after step 1, ...] of PolynomialLR(step_size=1, iter_warmup=0) (scheduler.py:24-41):
+    unchanged at last_epoch 0 and past iter_max, else (base - min)(1 - it/iter_max)^power + min."""
+    lrs, lr = [base_lr], base_lr
+    for it in range(1, steps + 1):
+        if it <= iter_max:
+            lr = (base_lr - min_lr) * (1 - it / iter_max) ** power + min_lr
+        lrs.append(lr)
+    return lrs

@@ -32,6 +32,11 @@ def full_golden():
 
 
 @pytest.fixture(scope="session")
+def train_golden():
+    return np.load(os.path.join(GOLDEN, "train_tail.npz"))
+
+
+@pytest.fixture(scope="session")
 def index_golden():
     return np.load(os.path.join(GOLDEN, "index_maps.npz"))
 

@@ -40,6 +40,29 @@ def test_library_exports_every_declared_symbol():
     assert lib.mumpy_abi_version() == 1
 
 
+def test_binding_argument_types_match_the_header():
+    """Every bound argument has the ctypes kind of its C declaration (a float/double or int/int64 slip corrupts the call)."""
+    from mumpy_hip.lib import SIGNATURES
+    decls = header_decls()
+
+    def kind(carg):
+        carg = carg.strip()
+        if "*" in carg:
+            return "ptr"
+        base = carg.rsplit(None, 1)[0] if " " in carg else carg
+        return {"int": "int", "int64_t": "i64", "float": "f32", "double": "f64"}[base.replace("const ", "").strip()]
+
+    def ckind(t):
+        if t is ctypes.c_void_p or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return "ptr"
+        return {ctypes.c_int: "int", ctypes.c_int64: "i64", ctypes.c_float: "f32", ctypes.c_double: "f64"}[t]
+
+    for name, args in SIGNATURES.items():
+        got = [ckind(t) for t in args]
+        want = [kind(a) for a in decls[name]]
+        assert got == want, f"{name}: binding {got} vs header {want}"
+
+
 def test_argument_validation_without_gpu():
     """Rejected arguments return negative codes before anything is launched, so this is safe on a CPU box."""
     from mumpy_hip.lib import load_library

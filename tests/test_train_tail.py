@@ -1,0 +1,192 @@
+"""SURVEY 8f-2 (config 5's training tail): mask loss fwd+bwd, PolynomialLR, parameter groups, fused AdamW, bucketed gradient
+all-reduce.  Goldens in tests/golden/train_tail.npz come from the reference's own utils/loss.py and
+utils/optimizer/scheduler.py (tests/golden/gen_train_goldens.py).  CPU tests pin the oracle and the host logic; the
+`gpu` tests run the HIP kernels through the C ABI."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import golden_input, rel_err
+from oracle import mumpy_oracle as O
+from weight_fill import seeded_randn
+
+HAS_GPU = torch.cuda.is_available()
+TAGS = ["toy", "odd", "full"]
+
+
+def _loss_case(g, tag):
+    ss = g[tag + "/seed_shape"]
+    seed, b, hw = int(ss[0]), int(ss[1]), [int(v) for v in ss[2:]]
+    z = seeded_randn(seed, b, *hw) * 2.0
+    t = (seeded_randn(seed + 50, b, 1, hw[1] * hw[2]) > 0.8).float()
+    return z, t
+
+
+# ----------------------------------------------------------------------------------------------------------- CPU
+@pytest.mark.parametrize("tag", TAGS)
+def test_oracle_mask_loss_matches_reference(train_golden, tag):
+    z, t = _loss_case(train_golden, tag)
+    z.requires_grad_(True)
+    tot, iou, foc = O.mask_loss(z, t)
+    (tot / 2.0).backward()                                      # the golden used accumulation_steps = 2
+    ref = train_golden[tag + "/loss3"]
+    assert abs(float(tot.detach()) / 2.0 - ref[0]) < 2e-6 and abs(float(iou.detach()) - ref[1]) < 2e-6 and abs(float(foc.detach()) - ref[2]) < 2e-6
+    assert rel_err(z.grad, train_golden[tag + "/dlogits"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["sched_a", "sched_b"])
+def test_polynomial_lr_matches_reference(train_golden, tag):
+    from mumpy_hip.train import polynomial_lr
+    base, iter_max = train_golden[tag + "/base_itermax"]
+    ref = train_golden[tag + "/lrs"]
+    lrs, lr = [base], base
+    for it in range(1, len(ref)):
+        lr = polynomial_lr(base, lr, it, int(iter_max))
+        lrs.append(lr)
+    assert np.allclose(lrs, ref, rtol=1e-12, atol=0)
+    assert np.allclose(O.polynomial_lr_sequence(base, int(iter_max), len(ref) - 1), ref, rtol=1e-12, atol=0)
+
+
+def test_param_groups_split_on_cva():
+    """train.py:198-213: encoder parameters with "cva" in the name get their own optimizer."""
+    from models.decoder.decoder import BaselineDecoder
+    from mumpy_hip.train import split_param_groups
+
+    class Enc(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.block = torch.nn.Linear(4, 4)
+            self.cva = torch.nn.Linear(4, 2)
+            self.frozen = torch.nn.Linear(2, 2)
+            self.frozen.weight.requires_grad_(False)
+    enc, dec = Enc(), BaselineDecoder(in_channels=32, features=[32] * 5)
+    g = split_param_groups(enc, dec)
+    assert [tuple(p.shape) for p in g["cva"]] == [(2, 4), (2,)]
+    assert [tuple(p.shape) for p in g["enc"]] == [(4, 4), (4,), (2,)]            # frozen.weight is filtered (utils.py:258)
+    assert len(g["dec"]) == len(list(dec.parameters()))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import PKG  # noqa: F401
+    from mumpy_hip import distributed as D
+    from mumpy_hip.train import FlatAdamW
+    D.init_process_group("gloo")
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))    # odd sizes: exercises the 16-B slot padding
+    opt = FlatAdamW(net.parameters(), lr=1e-3)
+    for i, p in enumerate(net.parameters()):
+        p.grad.copy_(torch.full_like(p, float((rank + 1) * (i + 1))))
+    scale = opt.all_reduce_grads(bucket_bytes=64)                                # 16-float buckets: several collectives
+    q.put((rank, scale, [float(p.grad.flatten()[0]) for p in net.parameters()],
+           bool(all(p.grad.data_ptr() >= opt.grad.data_ptr() for p in net.parameters()))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_grad_allreduce_two_ranks():
+    """world 2, gloo: the flat gradient buffer is summed bucket by bucket; AdamW then applies 1/world."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, scale, firsts, views in res:
+        assert scale == 0.5 and views
+        assert firsts == [3.0 * (i + 1) for i in range(4)]                        # (1 + 2) * (i + 1)
+
+
+# ----------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", TAGS)
+def test_hip_mask_loss_matches_reference(train_golden, tag):
+    from mumpy_hip import ops
+    z, t = _loss_case(train_golden, tag)
+    loss3, dz = ops.mask_loss(z.cuda(), t.cuda(), loss_scale=0.5)
+    ref = train_golden[tag + "/loss3"]
+    assert np.allclose(loss3.cpu().numpy(), ref, rtol=2e-5, atol=0)              # fp32 sums of 1e3..1e5 terms
+    assert dz.shape == z.shape
+    assert rel_err(dz.cpu(), train_golden[tag + "/dlogits"]) < 2e-5
+    loss_only, none = ops.mask_loss(z.cuda(), t.cuda(), need_grad=False, loss_scale=0.5)
+    assert none is None and torch.equal(loss_only, loss3)                         # deterministic, same reduction order
+    again, dz2 = ops.mask_loss(z.cuda(), t.cuda(), loss_scale=0.5)
+    assert torch.equal(dz2, dz) and torch.equal(again, loss3)
+
+
+@pytest.mark.gpu
+def test_hip_mask_loss_extremes():
+    """saturated logits (|z| = 40) and an all-background target: finite loss and gradient, equal to the oracle."""
+    from mumpy_hip import ops
+    z = seeded_randn(9, 2, 1, 32, 32) * 40.0
+    t = torch.zeros(2, 1, 1024)
+    t[1, 0, :100] = 1.0
+    zo = z.clone().requires_grad_(True)
+    tot, iou, foc = O.mask_loss(zo, t)
+    tot.backward()
+    loss3, dz = ops.mask_loss(z.cuda(), t.cuda())
+    assert torch.isfinite(loss3).all() and torch.isfinite(dz).all()
+    assert np.allclose(loss3.cpu().numpy(), [float(tot.detach()), float(iou.detach()), float(foc.detach())], rtol=3e-5)
+    assert rel_err(dz.cpu(), zo.grad) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 3, 4, 1023, 262147])
+def test_hip_adamw_matches_torch(n):
+    """torch.optim.AdamW (what utils/utils.py:258 builds) for 5 steps, weight decay and a gradient scale included."""
+    from mumpy_hip import ops
+    p0 = seeded_randn(21, n)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=3e-3, weight_decay=1e-2)
+    p, m, v = p0.cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 6):
+        g = seeded_randn(100 + step, n)
+        ref.grad = g * 0.5
+        opt.step()
+        ops.adamw_step(p, g.cuda(), m, v, step, lr=3e-3, weight_decay=1e-2, grad_scale=0.5)
+    assert rel_err(p.cpu(), ref.data) < 2e-6
+    st = opt.state[ref]
+    assert rel_err(m.cpu(), st["exp_avg"]) < 2e-6 and rel_err(v.cpu(), st["exp_avg_sq"]) < 2e-6
+
+
+@pytest.mark.gpu
+def test_flat_adamw_trains_like_torch_adamw():
+    """FlatAdamW over a module (params re-pointed at the flat buffer) == per-tensor torch.optim.AdamW, with the
+    polynomial schedule stepping both."""
+    from mumpy_hip.train import FlatAdamW, polynomial_lr
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
+    twin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3)).cuda()
+    twin.load_state_dict(net.state_dict())
+    ref = torch.optim.AdamW(twin.parameters(), lr=1e-2, weight_decay=1e-4)
+    opt = FlatAdamW(net.parameters(), lr=1e-2, weight_decay=1e-4)
+    x = seeded_randn(5, 16, 7).cuda()
+    for it in range(1, 9):
+        for model in (net, twin):
+            model(x).square().mean().backward()                  # autograd writes into the flat gradient views
+        assert all(p.grad.data_ptr() >= opt.grad.data_ptr() for p in net.parameters())
+        opt.step()
+        ref.step()
+        opt.zero_grad()
+        ref.zero_grad()
+        lr = opt.scheduler_step(iter_max=6)
+        for gparam in ref.param_groups:
+            gparam["lr"] = polynomial_lr(1e-2, gparam["lr"], it, 6)
+        assert lr == ref.param_groups[0]["lr"]
+    for a, b in zip(net.parameters(), twin.parameters()):
+        assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-5

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch one kernel shape repeatedly (for rocprofv3 --pmc / timing).
-  kernel_micro.py linear M N K [act]      | kernel_micro.py winattn B Hs W C shift | kernel_micro.py sample B Hs2 W C"""
+  kernel_micro.py linear M N K [act]      | kernel_micro.py winattn B Hs W C shift | kernel_micro.py sample B Hs2 W C
+  | kernel_micro.py adamw N | kernel_micro.py maskloss B P | kernel_micro.py ln rows C"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd")]
@@ -30,6 +31,16 @@ elif op == "sample":
     x2 = torch.randn(b, hs2 * w, c, device=dev); pos = torch.rand(nw, 3, 49, 2, device=dev) * 2 - 1
     fn = lambda: ops.deform_sample(x2, pos, b, hs2, w, c, nw)
     work, unit = 4.0 * (2 * nw * 49 * c + nw * 3 * 49 * 2), "GB/s"
+if op == "adamw":
+    n, = a
+    bufs = [torch.randn(n, device=dev) for _ in range(2)] + [torch.zeros(n, device=dev) for _ in range(2)]
+    fn = lambda: ops.adamw_step(bufs[0], bufs[1], bufs[2], bufs[3], 3, lr=1e-3)
+    work, unit = 28.0 * n, "GB/s"
+if op == "maskloss":
+    b, p_ = a
+    z = torch.randn(b, p_, device=dev); t = (torch.rand(b, p_, device=dev) < 0.1).float()
+    fn = lambda: ops.mask_loss(z, t)
+    work, unit = 20.0 * b * p_, "GB/s"
 if op == "ln":
     rows, c = a
     x = torch.randn(rows, c, device=dev); g = torch.ones(c, device=dev); b = torch.zeros(c, device=dev)
