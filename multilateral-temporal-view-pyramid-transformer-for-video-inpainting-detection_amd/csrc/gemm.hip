@@ -294,17 +294,20 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
         fread(0, afA, bfA);
         __syncthreads();                                         // everyone has chunk 0's fragments: buffer 0 is free
         if (nk > 2) gdma(kbeg + 2 * BK, 0);
-        for (int kc = 0; kc < nk; kc += 2) {
-            if (kc + 1 < nk) fread(1, afB, bfB);
+        // the pair loop has no exit in the middle (an odd last chunk is peeled): with a mid-loop `break` hipcc ping-pongs
+        // the accumulators between two register sets (s_nop 15 + 8 v_mov_b64 per pair of chunks)
+        int kc = 0;
+        for (; kc + 1 < nk; kc += 2) {
+            fread(1, afB, bfB);
             mma(afA, bfA);
             __syncthreads();                                     // chunk kc+2 landed; buffer 1 readers done
-            if (kc + 1 >= nk) break;
             if (kc + 3 < nk) gdma(kbeg + (kc + 3) * BK, 1);
             if (kc + 2 < nk) fread(0, afA, bfA);
             mma(afB, bfB);
             __syncthreads();
             if (kc + 4 < nk) gdma(kbeg + (kc + 4) * BK, 0);
         }
+        if (kc < nk) mma(afA, bfA);
     } else {
     f32x4 afB[TM][4], bfB[TN][4];
     gload(kbeg);
@@ -315,19 +318,20 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
     if (nk > 1) lstore(1);
     if (nk > 2) gload(kbeg + 2 * BK);
     __syncthreads();
-    for (int kc = 0; kc < nk; kc += 2) {
-        if (kc + 1 < nk && !(dbg & 4)) fread(1, afB, bfB);
+    int kc = 0;
+    for (; kc + 1 < nk; kc += 2) {                                // no mid-loop exit (see the DMA variant above)
+        if (!(dbg & 4)) fread(1, afB, bfB);
         mma(afA, bfA);
         if (kc + 2 < nk && !(dbg & 2)) lstore(0);
         if (kc + 3 < nk && !(dbg & 1)) gload(kbeg + (kc + 3) * BK);
         if (!(dbg & 8)) __syncthreads();
-        if (kc + 1 >= nk) break;
         if (kc + 2 < nk && !(dbg & 4)) fread(0, afA, bfA);
         mma(afB, bfB);
         if (kc + 3 < nk && !(dbg & 2)) lstore(1);
         if (kc + 4 < nk && !(dbg & 1)) gload(kbeg + (kc + 4) * BK);
         if (!(dbg & 8)) __syncthreads();
     }
+    if (kc < nk) mma(afA, bfA);                                   // odd last chunk: its fragments are already in set A
     }
     if (dbg & 16) { if (acc[0][0][0] == 12345.678f) Y[0] = 1.f; return; }
 
