@@ -11,8 +11,25 @@
 // chunk: MFMAs of chunk k issue from one register fragment set while the wave reads chunk k+1's fragments from LDS into
 // the other, writes chunk k+2 to LDS and issues the global loads (16 B per lane, 128-B row segments) of chunk k+3.
 // The epilogue (bias, exact-erf GELU, residual add) runs on the accumulators; stores are 128-B row segments.
-// Measured (tools/kernel_micro.py, MUMPY_GEMM_DBG ablation): the bare MFMA loop sustains ~124 TFLOP/s on MI355X (79 % of
-// the 157 TFLOP/s datasheet fp32-matrix peak); the full kernel reaches 90-105 on well-shaped problems.
+// Measured on MI355X (tools/kernel_micro.py, MUMPY_GEMM_DBG ablation, tools/micro/mfma_peak.hip, s_memtime/s_memrealtime
+// stamps in diagnostic builds):
+//   * a bare loop of this MFMA sustains 154-155 TFLOP/s at 2.38 GHz (random operands, 1-4 waves/SIMD, 1 dependent
+//     accumulator is enough); inside the GEMM the chip holds ~2.05 GHz (-> a 134 TFLOP/s ceiling), the kernel with every
+//     memory phase ablated runs at 125 and the full kernel at 85-117 depending on the shape.
+//   * per-CU timeline of the 64x64 kernel on M=7840 N=2048 K=512 (3936 blocks): a block lives 40 us = 1.9 prologue +
+//     26.8 main loop + 10.8 epilogue; on average 2.4 of the 4 resident blocks are inside their main loop and the matrix
+//     pipe is ~70 % busy.  The epilogue crawls (0.6 us per predicated row store) because its neighbours' MFMA streams
+//     hold the issue slots; a predicate-free interior path cut it to 4.5 us and the time reappeared in the neighbours'
+//     main loops (zero-sum, not kept).  Main-loop iterations themselves are MFMA-paced (4132 cycles per chunk for 4096
+//     cycles of MFMA on the SIMD).
+//   * tried and not kept: persistent blocks (+3-5 % on the 128x128 tile, spills on the 128-VGPR 64x64 tile), staggered
+//     first-round starts and s_setprio in the epilogue (no change), a 64x64-per-wave DMA variant with register-pipelined
+//     fragments (spills at 2 waves/SIMD, slower at 1), and a from-scratch structure after the cdna guide's "pipelining
+//     across barriers" (4-stage LDS-DMA ring with counted vmcnt + raw s_barrier, ping-pong wave groups, persistent,
+//     next item's prologue under the epilogue): bit-correct, MFMA-only 125 us / + fragment reads 137 / + DMA 154-163 on
+//     M=7840 N=512 K=2048, i.e. it TIES the kernels here on the large shapes (162 vs 159 us, 188 vs 186 us) and loses on
+//     small grids.  Structurally different kernels converging on the same rate says the limiter is the clock the chip
+//     holds under fp32-MFMA-plus-operand-traffic load, so the remaining lever is energy per MFMA (bytes moved per MFMA).
 #include <stdlib.h>
 #include "common.h"
 using namespace mumpy;
