@@ -212,6 +212,36 @@ int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
                      void* stream);
 
+/* ---- backward kernels of the Swin block (rows 5-7 of 8a in training) ---------------------------------
+ * LayerNorm backward (swin:266,305): x, dy, dx (rows,C); gamma, dgamma, dbeta (C); C % 4 == 0, C <= 1024.
+ * workspace: mumpy_layernorm_bwd_workspace_bytes(rows, C) bytes of device scratch.  Deterministic. */
+int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C);
+int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
+                        void* workspace, int64_t workspace_bytes, int64_t rows, int C, float eps, void* stream);
+
+/* exact-erf GELU (nn.GELU(), swin:42) as its own kernel for training, where the pre-activation must be kept:
+ * y = gelu(x);  dx = dy * gelu'(x).  n % 4 == 0. */
+int mumpy_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
+int mumpy_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+
+/* out (C,R) = in (R,C)^T: operand layout for the weight-gradient GEMMs (dW = dY^T X = linear(dY^T, X^T)). */
+int mumpy_transpose_fwd(const float* in, float* out, int64_t R, int64_t C, void* stream);
+
+/* out[c] = sum_r x[r][c] (bias gradients), fixed-order two-stage reduction; workspace from the _bytes query. */
+int64_t mumpy_col_sum_workspace_bytes(int64_t R, int C);
+int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, int64_t workspace_bytes, int64_t R, int C, void* stream);
+
+/* window attention backward (row 5 of 8a in training; swin:145-163 differentiated): qkv (B,Hs*W,3C) and dout (B,Hs*W,C)
+ * in raster order as in the forward, bias / mask_tab / mask_id as in the forward, rel_index = the (49*49) int32 image of
+ * `relative_position_index`.  Writes dqkv (B,Hs*W,3C) (every element) and dtable (169, C/32) = gradient of
+ * `relative_position_bias_table`.  P is recomputed from q,k (nothing else is kept from the forward).  Deterministic.
+ * workspace: mumpy_window_attention_bwd_workspace_bytes(B,Hs,W,C) bytes of device scratch. */
+int64_t mumpy_window_attention_bwd_workspace_bytes(int B, int Hs, int W, int C);
+int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
+                               const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv, float* dtable,
+                               void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C, int shift, float scale,
+                               void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,7 +90,7 @@ __device__ __forceinline__ void qk_product(f32x16 (&s)[2], const f32x4 (&kf)[2][
 // windows run branch-free and a masked window issues its 7 mask loads back to back (one wait) instead of load-wait pairs.
 template <bool MASKED, typename BIAS>
 __device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const float* mask_w, int i, int h,
-                                             float post_scale) {
+                                             float post_scale, float* m_out = nullptr, float* inv_out = nullptr) {
     constexpr float NEG = -1e30f;
 #pragma unroll
     for (int jt = 0; jt < 2; ++jt)
@@ -150,6 +150,7 @@ __device__ __forceinline__ void bias_softmax(f32x16 (&s)[2], BIAS bias_at, const
             if (jt == 1 && r >= 9) continue;
             s[jt][r] *= inv;
         }
+    if (m_out) { *m_out = m; *inv_out = inv; }
 }
 
 // the 25 (jt,g,e) MFMA steps of P V that can hold a key < 49; key of lane half h is 32jt+8g+4h+e
@@ -375,6 +376,308 @@ __global__ __launch_bounds__(256, 2) void win_attn_cross_kernel(CrossArgs a) {
     store_o(o[1], 1, [&](int i) { return obase + (int64_t)i * a.C; }, c, h);
 }
 
+// ===============================================================================================================
+// BACKWARD of the window attention core ("backward HIP kernels for row 5").  Given dO, the unit's
+// P = softmax(q k^T + bias + mask) is recomputed (nothing but q/k/v is kept from the forward) and
+//   dV = P^T dO,   dP = dO V^T,   dS = P o (dP - rowsum(P o dP)),   dQ = scale dS K,   dK = dS^T (scale Q),   dBias += dS.
+// Two kernels, one per MFMA orientation, so that every product gets its A operand straight from accumulator registers
+// (the forward's accumulator->operand trick) and nothing is transposed through LDS:
+//   bwd_q : lane = QUERY (S^T = K Q^T as in the forward): softmax statistics, D = rowsum(P o dP), dS^T, dQ = dS K, and the
+//           per-wave running sum of dS for the bias gradient; writes {m, 1/l, D} per query for the second kernel.
+//   bwd_kv: lane = KEY (S = Q K^T, the same fragments with the MFMA operands swapped): P and dS rebuilt from the saved
+//           statistics, dV = P^T dO and dK = dS^T Q accumulated over the queries.
+// One wave per (window, head) unit, persistent blocks of 4 waves per head as in the forward; 1 wave per SIMD (the
+// operand sets of a unit need ~300 VGPRs).  Deterministic: per-wave dBias partials are reduced in a fixed order.
+struct BwdArgs {
+    const float* qkv; const float* dout; const float* bias; const float* mask_tab; const int32_t* mask_id;
+    float* dqkv; float* stats; float* dbias_part;
+    int B, Hs, W, C, nH, shift, nWx, nW, n_mask, groups;
+    float scale;
+};
+
+// 16 consecutive channels [16h, 16h+16) of a 32-channel head row (MFMA A/B fragment layout of the forward)
+__device__ __forceinline__ void load_frag16(f32x4 (&f)[4], const char* base, uint32_t off) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = *reinterpret_cast<const f32x4*>(base + (off + 16u * i));
+}
+
+__global__ __launch_bounds__(256, 1) void win_attn_bwd_q_kernel(BwdArgs a) {
+    __shared__ uint32_t tok_in[4][64];
+    __shared__ uint32_t tok_out[4][64];
+    __shared__ __attribute__((aligned(16))) float bias_s[WT * BLD];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x % a.nH;
+    const int slot = blockIdx.x / a.nH;
+    const int64_t nwin = (int64_t)a.B * a.nW;
+    {
+        const float* bsrc = a.bias + (int64_t)head * 4096;
+        for (int idx = threadIdx.x; idx < WT * 16; idx += 256) {
+            const int row = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(&bias_s[row * BLD + 4 * c4]) = *reinterpret_cast<const f32x4*>(bsrc + row * 64 + 4 * c4);
+        }
+    }
+    __syncthreads();
+    const int64_t L = (int64_t)a.Hs * a.W;
+    const uint32_t rsb = 12u * a.C, rob = 4u * a.C;
+    uint32_t* ti = tok_in[wave];
+    uint32_t* to = tok_out[wave];
+    f32x16 dsum[2][2];                                                    // running sum of dS^T over this wave's units
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dsum[it][jt][r] = 0.f;
+
+    for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {
+        const int n = (int)(bw % a.nW);
+        const int64_t b = bw / a.nW;
+        const int wy = n / a.nWx, wx = n - wy * a.nWx;
+        {
+            const uint32_t tok = (uint32_t)window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);
+            ti[lane] = tok * rsb;
+            to[lane] = tok * rob;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const char* qb = reinterpret_cast<const char*>(a.qkv + b * L * 3 * a.C + head * HD);
+        const char* kb = qb + 4 * a.C;
+        const char* vb = qb + 8 * a.C;
+        const char* dob = reinterpret_cast<const char*>(a.dout + b * L * a.C + head * HD);
+        f32x4 qf[2][4], kf[2][4], vkf[2][4], dof[2][4];
+        float kv[2][16];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t off = ti[32 * t + c] + 64u * h;
+            load_frag16(qf[t], qb, off);
+            load_frag16(kf[t], kb, off);
+            load_frag16(vkf[t], vb, off);
+            load_frag16(dof[t], dob, to[32 * t + c] + 64u * h);
+        }
+        for_pv_steps([&](int jt, int g, int e) {
+            kv[jt][4 * g + e] = *reinterpret_cast<const float*>(kb + (ti[32 * jt + 8 * g + 4 * h + e] + 4u * c));
+        });
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qf[t][i] *= a.scale;
+        const float* mask_w = nullptr;
+        if (a.mask_id) {
+            const int id = a.mask_id[bw % a.n_mask];
+            if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
+        }
+        char* dqb = reinterpret_cast<char*>(a.dqkv + b * L * 3 * a.C + head * HD);
+        float* st = a.stats + (bw * a.nH + head) * 192;                   // {m[64], inv[64], D[64]} of this unit
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            f32x16 s[2], dp[2];
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[jt][r] = 0.f; dp[jt][r] = 0.f; }
+            qk_product(s, kf, qf[it]);                                    // S^T = K Q^T
+            const int qi = 32 * it + c;
+            const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];
+            auto bias_at = [&](int jt, int g) {
+                f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
+                if (jt == 1 && g == 2 && h) bv.x = -1e30f;
+                return bv;
+            };
+            float m, inv;
+            if (mask_w) bias_softmax<true>(s, bias_at, mask_w, qi, h, 1.0f, &m, &inv);
+            else bias_softmax<false>(s, bias_at, nullptr, qi, h, 1.0f, &m, &inv);
+            qk_product(dp, vkf, dof[it]);                                 // dP^T = V dO^T
+            float d = 0.f;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (jt == 1 && r >= 9) continue;                      // P == 0 on padded keys
+                    d += s[jt][r] * dp[jt][r];
+                }
+            d += __shfl_xor(d, 32);
+            const bool qvalid = qi < WT;
+#pragma unroll
+            for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (jt == 1 && r >= 9) { s[jt][r] = 0.f; continue; }
+                    const float ds = qvalid ? s[jt][r] * (dp[jt][r] - d) : 0.f;    // padded queries contribute nothing
+                    s[jt][r] = ds;
+                    dsum[it][jt][r] += ds;
+                }
+            if (h == 0 && qvalid) { st[qi] = m; st[64 + qi] = inv; st[128 + qi] = d; }
+            f32x16 o;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] = 0.f;
+            pv_product(o, s, kv);                                         // dQ = dS K   (rows = queries, lanes = channels)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;
+                const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (i < WT) *reinterpret_cast<float*>(dqb + (ti[i] + 4u * c)) = o[r] * a.scale;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    float* part = a.dbias_part + ((int64_t)blockIdx.x * 4 + wave) * 4096;  // [it][jt][r][lane]
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[((it * 2 + jt) * 16 + r) * 64 + lane] = dsum[it][jt][r];
+}
+
+__global__ __launch_bounds__(256, 1) void win_attn_bwd_kv_kernel(BwdArgs a) {
+    __shared__ uint32_t tok_in[4][64];
+    __shared__ uint32_t tok_out[4][64];
+    __shared__ __attribute__((aligned(16))) float biasT_s[WT * BLD];      // bias^T: row = key j, column = query i
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int head = blockIdx.x % a.nH;
+    const int slot = blockIdx.x / a.nH;
+    const int64_t nwin = (int64_t)a.B * a.nW;
+    {
+        const float* bsrc = a.bias + (int64_t)head * 4096;
+        for (int idx = threadIdx.x; idx < WT * WT; idx += 256) {
+            const int i = idx / WT, j = idx - i * WT;
+            biasT_s[j * BLD + i] = bsrc[i * 64 + j];
+        }
+        for (int idx = threadIdx.x; idx < WT * (64 - WT); idx += 256) {   // query columns 49..63 of every key row: finite filler
+            const int j = idx / (64 - WT), i = WT + idx % (64 - WT);
+            biasT_s[j * BLD + i] = 0.f;
+        }
+    }
+    __syncthreads();
+    const int64_t L = (int64_t)a.Hs * a.W;
+    const uint32_t rsb = 12u * a.C, rob = 4u * a.C;
+    uint32_t* ti = tok_in[wave];
+    uint32_t* to = tok_out[wave];
+    for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {
+        const int n = (int)(bw % a.nW);
+        const int64_t b = bw / a.nW;
+        const int wy = n / a.nWx, wx = n - wy * a.nWx;
+        {
+            const uint32_t tok = (uint32_t)window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);
+            ti[lane] = tok * rsb;
+            to[lane] = tok * rob;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const char* qb = reinterpret_cast<const char*>(a.qkv + b * L * 3 * a.C + head * HD);
+        const char* kb = qb + 4 * a.C;
+        const char* vb = qb + 8 * a.C;
+        const char* dob = reinterpret_cast<const char*>(a.dout + b * L * a.C + head * HD);
+        f32x4 qf[2][4], kf[2][4], vkf[2][4], dof[2][4];
+        float qv[2][16], dov[2][16];                                      // query-order operands: [it][4g+e] = row 32it+8g+4h+e, lane = channel
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const uint32_t off = ti[32 * t + c] + 64u * h;
+            load_frag16(qf[t], qb, off);
+            load_frag16(kf[t], kb, off);
+            load_frag16(vkf[t], vb, off);
+            load_frag16(dof[t], dob, to[32 * t + c] + 64u * h);
+        }
+        for_pv_steps([&](int it, int g, int e) {
+            const int i = 32 * it + 8 * g + 4 * h + e;
+            qv[it][4 * g + e] = *reinterpret_cast<const float*>(qb + (ti[i] + 4u * c)) * a.scale;
+            dov[it][4 * g + e] = *reinterpret_cast<const float*>(dob + (to[i] + 4u * c));
+        });
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qf[t][i] *= a.scale;
+        const float* mask_w = nullptr;
+        if (a.mask_id) {
+            const int id = a.mask_id[bw % a.n_mask];
+            if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
+        }
+        char* dkb = reinterpret_cast<char*>(a.dqkv + b * L * 3 * a.C + head * HD) + 4 * a.C;
+        char* dvb = dkb + 4 * a.C;
+        const float* st = a.stats + (bw * a.nH + head) * 192;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt) {
+            f32x16 s[2], dp[2];                                           // [query tile it]: lane = key 32jt+c, rows = queries
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { s[it][r] = 0.f; dp[it][r] = 0.f; }
+            qk_product(s, qf, kf[jt]);                                    // S = Q K^T   (A = q rows, B = k rows)
+            qk_product(dp, dof, vkf[jt]);                                 // dP = dO V^T
+            const int kj = 32 * jt + c;
+            const int kjc = kj < WT ? kj : WT - 1;
+            const float* brow = &biasT_s[kjc * BLD + 4 * h];
+#pragma unroll
+            for (int it = 0; it < 2; ++it)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (it == 1 && g == 3) {                              // queries 56..63: padding
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s[it][4 * g + e] = 0.f; dp[it][4 * g + e] = 0.f; }
+                        continue;
+                    }
+                    const int i0 = 32 * it + 8 * g + 4 * h;               // this lane's 4 consecutive queries i0 .. i0+3
+                    f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * it + 8 * g);
+                    if (mask_w) bv += *reinterpret_cast<const f32x4*>(mask_w + kjc * 64 + i0);   // mask is symmetric in (i, j)
+                    const f32x4 mv = *reinterpret_cast<const f32x4*>(st + i0);
+                    const f32x4 iv = *reinterpret_cast<const f32x4*>(st + 64 + i0);
+                    const f32x4 dv = *reinterpret_cast<const f32x4*>(st + 128 + i0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const bool valid = (i0 + e < WT) && (kj < WT);
+                        const float pr = valid ? __expf(s[it][4 * g + e] + bv[e] - mv[e]) * iv[e] : 0.f;
+                        s[it][4 * g + e] = pr;                                             // P
+                        dp[it][4 * g + e] = valid ? pr * (dp[it][4 * g + e] - dv[e]) : 0.f;   // dS
+                    }
+                }
+            f32x16 ov, ok;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ov[r] = 0.f; ok[r] = 0.f; }
+            pv_product(ov, s, dov);                                       // dV = P^T dO   (sum over queries)
+            pv_product(ok, dp, qv);                                       // dK = dS^T (scale Q)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (jt == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;
+                const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (j < WT) {
+                    *reinterpret_cast<float*>(dvb + (ti[j] + 4u * c)) = ov[r];
+                    *reinterpret_cast<float*>(dkb + (ti[j] + 4u * c)) = ok[r];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// dbias_full[head][i][j] = sum over that head's wave partials (fixed order); partial layout [it][jt][r][lane]
+__global__ __launch_bounds__(256) void win_attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ full, int nH,
+                                                                    int nblocks) {
+    const int head = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;                       // element of the 4096-float partial
+    if (idx >= 4096) return;
+    float s = 0.f;
+    for (int blk = head; blk < nblocks; blk += nH)
+        for (int w = 0; w < 4; ++w) s += part[((int64_t)blk * 4 + w) * 4096 + idx];
+    const int lane = idx & 63, r = (idx >> 6) & 15, jt = (idx >> 10) & 1, it = idx >> 11;
+    const int i = 32 * it + (lane & 31), j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    full[(int64_t)head * 4096 + i * 64 + j] = s;
+}
+
+// dtable[t][head] = sum over the (i, j) pairs with relative_position_index[i][j] == t, in (i, j) order
+__global__ __launch_bounds__(256) void win_attn_dtable_kernel(const float* __restrict__ full, const int32_t* __restrict__ rel_index,
+                                                              float* __restrict__ dtable, int nH, int ntab) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int head = blockIdx.y;
+    if (t >= ntab) return;
+    float s = 0.f;
+    for (int i = 0; i < WT; ++i)
+        for (int j = 0; j < WT; ++j)
+            if (rel_index[i * WT + j] == t) s += full[(int64_t)head * 4096 + i * 64 + j];
+    dtable[(int64_t)t * nH + head] = s;
+}
+
 }  // namespace
 
 extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
@@ -427,5 +730,58 @@ extern "C" int mumpy_deform_attention_fwd(const float* q, const float* kv, const
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "deform_attention: too many windows");
     hipLaunchKernelGGL(win_attn_cross_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("deform_attention");
+    return 0;
+}
+
+static int64_t wa_bwd_groups(int B, int nW, int nH) {
+    const int64_t quads = ((int64_t)B * nW + 3) / 4;
+    int64_t groups = (256 + nH - 1) / nH;                 // ~one 4-wave block per CU (1 wave per SIMD)
+    return groups > quads ? quads : groups;
+}
+
+extern "C" int64_t mumpy_window_attention_bwd_workspace_bytes(int B, int Hs, int W, int C) {
+    if (B <= 0 || Hs <= 0 || W <= 0 || C <= 0 || Hs % WS || W % WS || C % HD) return 0;
+    const int nW = (Hs / WS) * (W / WS), nH = C / HD;
+    const int64_t stats = (int64_t)B * nW * nH * 192;
+    const int64_t part = wa_bwd_groups(B, nW, nH) * nH * 4 * 4096;
+    return (stats + part + (int64_t)nH * 4096) * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
+                                          const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv,
+                                          float* dtable, void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C,
+                                          int shift, float scale, void* stream) {
+    MUMPY_REQUIRE(qkv && dout && bias && rel_index && dqkv && dtable && workspace, MUMPY_ENULL, "window_attention_bwd: null pointer");
+    MUMPY_REQUIRE((mask_tab == nullptr) == (mask_id == nullptr), MUMPY_ENULL,
+                  "window_attention_bwd: mask_tab and mask_id must be given together");
+    MUMPY_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(bias) && aligned16(mask_tab) && aligned16(dqkv) &&
+                      aligned16(workspace), MUMPY_EALIGN, "window_attention_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && Hs > 0 && W > 0 && Hs % WS == 0 && W % WS == 0, MUMPY_EINVAL,
+                  "window_attention_bwd: grid (%d,%d) not divisible by window 7", Hs, W);
+    MUMPY_REQUIRE(C > 0 && C % HD == 0 && shift >= 0 && shift < WS, MUMPY_EINVAL, "window_attention_bwd: bad C=%d / shift=%d", C, shift);
+    MUMPY_REQUIRE(mask_id == nullptr || n_mask > 0, MUMPY_EINVAL, "window_attention_bwd: n_mask must be > 0 with a mask");
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_window_attention_bwd_workspace_bytes(B, Hs, W, C), MUMPY_EINVAL,
+                  "window_attention_bwd: workspace too small");
+    BwdArgs a;
+    a.qkv = qkv; a.dout = dout; a.bias = bias; a.mask_tab = mask_tab; a.mask_id = mask_id; a.dqkv = dqkv;
+    a.B = B; a.Hs = Hs; a.W = W; a.C = C; a.nH = C / HD; a.shift = shift; a.nWx = W / WS; a.nW = (Hs / WS) * (W / WS);
+    a.n_mask = n_mask > 0 ? n_mask : 1; a.scale = scale;
+    a.groups = (int)wa_bwd_groups(B, a.nW, a.nH);
+    float* ws = static_cast<float*>(workspace);
+    a.stats = ws;
+    a.dbias_part = ws + (int64_t)B * a.nW * a.nH * 192;
+    float* full = a.dbias_part + (int64_t)a.groups * a.nH * 4 * 4096;
+    const unsigned grid = (unsigned)(a.groups * a.nH);
+    hipLaunchKernelGGL(win_attn_bwd_q_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    MUMPY_CHECK_LAUNCH("window_attention_bwd(q)");
+    hipLaunchKernelGGL(win_attn_bwd_kv_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
+    MUMPY_CHECK_LAUNCH("window_attention_bwd(kv)");
+    hipLaunchKernelGGL(win_attn_dbias_reduce_kernel, dim3(16, a.nH), dim3(256), 0, as_stream(stream), a.dbias_part, full, a.nH,
+                       (int)grid);
+    MUMPY_CHECK_LAUNCH("window_attention_bwd(dbias reduce)");
+    const int ntab = (2 * WS - 1) * (2 * WS - 1);
+    hipLaunchKernelGGL(win_attn_dtable_kernel, dim3((ntab + 255) / 256, a.nH), dim3(256), 0, as_stream(stream), full, rel_index, dtable,
+                       a.nH, ntab);
+    MUMPY_CHECK_LAUNCH("window_attention_bwd(dtable)");
     return 0;
 }

@@ -40,6 +40,15 @@ SIGNATURES = {
     "mumpy_normalize_u8_fwd": [c_f, c_f, c_l, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f],
     "mumpy_mask_loss_workspace_bytes": [c_i, c_l],
     "mumpy_mask_loss_fwd_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_fl, c_fl, c_f],
+    "mumpy_layernorm_bwd_workspace_bytes": [c_l, c_i],
+    "mumpy_layernorm_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_fl, c_f],
+    "mumpy_gelu_fwd": [c_f, c_f, c_l, c_f],
+    "mumpy_gelu_bwd": [c_f, c_f, c_f, c_l, c_f],
+    "mumpy_transpose_fwd": [c_f, c_f, c_l, c_l, c_f],
+    "mumpy_col_sum_workspace_bytes": [c_l, c_i],
+    "mumpy_col_sum_fwd": [c_f, c_f, c_f, c_l, c_l, c_i, c_f],
+    "mumpy_window_attention_bwd_workspace_bytes": [c_i, c_i, c_i, c_i],
+    "mumpy_window_attention_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }
 ABI_VERSION = 1

@@ -393,3 +393,80 @@ def adamw_step(param, grad, exp_avg, exp_avg_sq, step, lr, betas=(0.9, 0.999), e
     _call("mumpy_adamw_step", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, lr, betas[0], betas[1], eps, weight_decay,
           int(step), grad_scale, _stream(), work=28.0 * n)
     return param
+
+
+# ------------------------------------------------------------------------------------------ Swin block backward (8f-2)
+def _ws(nbytes, device):
+    return torch.empty(max(nbytes // 4, 4), device=device, dtype=torch.float32)
+
+
+def layernorm_bwd(x, gamma, dy, eps=1e-5):
+    """-> (dx like x, dgamma (C), dbeta (C)) of nn.LayerNorm over the last dim."""
+    x, dy, gamma = _chk(x, "x"), _chk(dy, "dy"), _chk(gamma, "gamma")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, device=x.device, dtype=torch.float32)
+    db = torch.empty(c, device=x.device, dtype=torch.float32)
+    wsb = int(_lib().mumpy_layernorm_bwd_workspace_bytes(rows, c))
+    ws = _ws(wsb, x.device)
+    _call("mumpy_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dx), _p(dg), _p(db), _p(ws), wsb, rows, c, eps, _stream(),
+          work=12.0 * x.numel())
+    return dx, dg, db
+
+
+def gelu(x):
+    x = _chk(x, "x")
+    y = torch.empty_like(x)
+    _call("mumpy_gelu_fwd", _p(x), _p(y), x.numel(), _stream(), work=8.0 * x.numel())
+    return y
+
+
+def gelu_bwd(x, dy):
+    x, dy = _chk(x, "x"), _chk(dy, "dy")
+    dx = torch.empty_like(x)
+    _call("mumpy_gelu_bwd", _p(x), _p(dy), _p(dx), x.numel(), _stream(), work=12.0 * x.numel())
+    return dx
+
+
+def transpose(x2d, pad_rows_to=1):
+    """(R,C) -> (C, Rp) with Rp = R rounded up to a multiple of `pad_rows_to` (extra columns zero): the K-contiguous
+    operand layout of the weight-gradient GEMMs, whose reduction dim (the token count) must be a multiple of 32."""
+    x2d = _chk(x2d, "x")
+    r, c = x2d.shape
+    rp = (r + pad_rows_to - 1) // pad_rows_to * pad_rows_to
+    if rp != r:
+        xp = torch.zeros(rp, c, device=x2d.device, dtype=torch.float32)
+        xp[:r] = x2d
+        x2d, r = xp, rp
+    out = torch.empty(c, r, device=x2d.device, dtype=torch.float32)
+    _call("mumpy_transpose_fwd", _p(x2d), _p(out), r, c, _stream(), work=8.0 * x2d.numel())
+    return out
+
+
+def col_sum(x2d):
+    x2d = _chk(x2d, "x")
+    r, c = x2d.shape
+    out = torch.empty(c, device=x2d.device, dtype=torch.float32)
+    wsb = int(_lib().mumpy_col_sum_workspace_bytes(r, c))
+    ws = _ws(wsb, x2d.device)
+    _call("mumpy_col_sum_fwd", _p(x2d), _p(out), _p(ws), wsb, r, c, _stream(), work=4.0 * x2d.numel())
+    return out
+
+
+def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None):
+    """-> (dqkv (B, hs*w, 3C), dtable (169, C/32)): gradients of the W-MSA core wrt qkv and the relative position bias table."""
+    qkv, dout = _chk(qkv, "qkv"), _chk(dout, "dout")
+    if qkv.numel() != b * hs * w * 3 * c or dout.numel() != b * hs * w * c:
+        raise RuntimeError("window_attention_bwd: shape mismatch")
+    if rel_index32.dtype != torch.int32 or rel_index32.numel() != 49 * 49 or not rel_index32.is_cuda:
+        raise RuntimeError("window_attention_bwd: rel_index32 must be the (49*49) int32 relative_position_index on the GPU")
+    dqkv = torch.empty_like(qkv)
+    dtable = torch.empty(169, c // 32, device=qkv.device, dtype=torch.float32)
+    wsb = int(_lib().mumpy_window_attention_bwd_workspace_bytes(b, hs, w, c))
+    ws = _ws(wsb, qkv.device)
+    n_mask = 0 if mask_id is None else mask_id.numel()
+    _call("mumpy_window_attention_bwd", _p(qkv), _p(dout), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
+          _p(rel_index32.contiguous()), _p(dqkv), _p(dtable), _p(ws), wsb, b, hs, w, c, shift, scale, _stream(),
+          work=5 * 153664.0 * b * (hs // 7) * (w // 7) * (c // 32))
+    return dqkv, dtable

@@ -133,28 +133,37 @@ def tokenize(x: torch.Tensor, sd: SD, cfg: MumpyConfig, p: str = "base.tokenize"
 # ----------------------------------------------------------------------------------------------
 # rows 4-5: window attention on a raster-ordered token tensor
 # ----------------------------------------------------------------------------------------------
-def window_attention(xn: torch.Tensor, sd: SD, p: str, hs: int, w: int, shift: int,
-                     mask: Optional[torch.Tensor]) -> torch.Tensor:
-    """xn (B, hs*w, C) already LayerNorm-ed; returns W-MSA output in raster order (swin:134-166, 266-301)."""
-    b, l, c = xn.shape
+def window_attention_core(qkv: torch.Tensor, table: torch.Tensor, rel_index: torch.Tensor, hs: int, w: int, shift: int,
+                          mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """The part of WindowAttention.forward between the two Linears (swin:143-163) on raster-ordered qkv (B, hs*w, 3C):
+    window partition + roll folded into `idx`, q*scale, q k^T + relative position bias (+ shift mask), softmax, @ v,
+    window reverse.  Returns (B, hs*w, C) raster.  Differentiable in qkv and table (used as the backward oracle)."""
+    b, l, c3 = qkv.shape
+    c = c3 // 3
     nh = c // HEAD_DIM
     idx = window_token_index(hs, w, shift)
-    xw = xn[:, idx].reshape(-1, WS * WS, c)                   # (B*nW,49,C)
-    qkv = _lin(xw, sd, p + ".qkv").reshape(-1, 49, 3, nh, HEAD_DIM).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * (HEAD_DIM ** -0.5), qkv[1], qkv[2]     # scale on q first (swin:145)
+    qw = qkv[:, idx].reshape(-1, WS * WS, 3, nh, HEAD_DIM).permute(2, 0, 3, 1, 4)     # (3, B*nW, nH, 49, 32)
+    q, k, v = qw[0] * (HEAD_DIM ** -0.5), qw[1], qw[2]         # scale on q first (swin:145)
     attn = q @ k.transpose(-2, -1)
-    rpi = sd[p + ".relative_position_index"].reshape(-1)
-    bias = sd[p + ".relative_position_bias_table"][rpi].view(49, 49, nh).permute(2, 0, 1)
+    bias = table[rel_index.reshape(-1)].view(49, 49, nh).permute(2, 0, 1)
     attn = attn + bias.unsqueeze(0)
     if mask is not None:
         nw = mask.shape[0]
         attn = (attn.view(-1, nw, nh, 49, 49) + mask.view(1, nw, 1, 49, 49)).view(-1, nh, 49, 49)
     attn = attn.softmax(-1)
-    y = (attn @ v).transpose(1, 2).reshape(-1, 49, c)
-    y = _lin(y, sd, p + ".proj").reshape(b, l, c)
+    y = (attn @ v).transpose(1, 2).reshape(b, l, c)
     out = torch.empty_like(y)
     out[:, idx] = y                                           # window_reverse + roll back
     return out
+
+
+def window_attention(xn: torch.Tensor, sd: SD, p: str, hs: int, w: int, shift: int,
+                     mask: Optional[torch.Tensor]) -> torch.Tensor:
+    """xn (B, hs*w, C) already LayerNorm-ed; returns W-MSA output in raster order (swin:134-166, 266-301).  The two
+    Linears are per-token, so applying them before the window gather / after the scatter is the same computation."""
+    a = window_attention_core(_lin(xn, sd, p + ".qkv"), sd[p + ".relative_position_bias_table"],
+                              sd[p + ".relative_position_index"], hs, w, shift, mask)
+    return _lin(a, sd, p + ".proj")
 
 
 def mlp(x, sd: SD, p: str):

@@ -29,6 +29,13 @@ def main():
     open(os.path.join(d, "timm", "scheduler", "__init__.py"), "w").close()
     with open(os.path.join(d, "timm", "scheduler", "scheduler.py"), "w") as f:
         f.write("class Scheduler:\n    pass\n")
+    from gen_goldens import STUB_MLC, STUB_TIMM                  # the model-side stand-ins, same text as gen_goldens.py
+    os.makedirs(os.path.join(d, "timm", "models"))
+    open(os.path.join(d, "timm", "models", "__init__.py"), "w").close()
+    with open(os.path.join(d, "timm", "models", "layers.py"), "w") as f:
+        f.write(STUB_TIMM)
+    with open(os.path.join(d, "ml_collections.py"), "w") as f:
+        f.write(STUB_MLC)
     sys.path.insert(0, d)
     sys.path.insert(0, args.ref)
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -63,6 +70,23 @@ def main():
         store[f"{tag}/base_itermax"] = np.array([base, iter_max], dtype=np.float64)
         store[f"{tag}/lrs"] = np.array(lrs, dtype=np.float64)
         print(tag, lrs[:3], lrs[-3:])
+    # SwinTransformerBlock forward + backward through the reference's own module and torch autograd (swin:185-307):
+    # x (2, 14*14, 96), 3 heads, shift 0 and 3; loss = sum(y * g) with a seeded cotangent g
+    from weight_fill import fill_module_
+    from models.modules.swinTransformer import SwinTransformerBlock
+    for tag, shift in (("blk_s0", 0), ("blk_s3", 3)):
+        blk = SwinTransformerBlock(dim=96, input_resolution=(14, 14), num_heads=3, window_size=7, shift_size=shift)
+        fill_module_(blk)
+        blk.eval()                                           # DropPath is Identity at rate 0 either way
+        x = seeded_randn(700 + shift, 2, 196, 96).requires_grad_(True)
+        g = seeded_randn(710 + shift, 2, 196, 96)
+        y = blk(x)
+        (y * g).sum().backward()
+        store[f"{tag}/y"] = y.detach().numpy().astype(np.float32)
+        store[f"{tag}/dx"] = x.grad.numpy().astype(np.float32)
+        for name, prm in blk.named_parameters():
+            store[f"{tag}/grad/{name}"] = prm.grad.numpy().astype(np.float32)
+        print(tag, float(y.abs().max()), float(x.grad.abs().max()), len(list(blk.named_parameters())), "param grads")
     np.savez_compressed(os.path.join(args.out, "train_tail.npz"), **store)
     print("train_tail.npz", os.path.getsize(os.path.join(args.out, "train_tail.npz")) // 1024, "KiB")
 

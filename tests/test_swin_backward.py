@@ -1,0 +1,136 @@
+"""SURVEY 8f-2, first slice: backward of the Swin block (rows 5-7 of 8a) on HIP kernels.  Goldens (`blk_s0`, `blk_s3` in
+tests/golden/train_tail.npz) are the reference's own SwinTransformerBlock run forward + backward under torch autograd
+(tests/golden/gen_train_goldens.py).  CPU: the oracle under autograd reproduces them.  GPU: every backward kernel against
+torch autograd of the same op, and the whole block through mumpy_hip.autograd against the goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from oracle import mumpy_oracle as O
+from weight_fill import fill_module_, seeded_randn
+
+TAGS = [("blk_s0", 0), ("blk_s3", 3)]
+GRAD_TOL = 2e-4            # fp32, sums over 392 tokens / 49 keys in a different order than torch's
+
+
+def _block(shift):
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = SwinTransformerBlock(dim=96, input_resolution=(14, 14), num_heads=3, window_size=7, shift_size=shift)
+    return fill_module_(blk).eval()
+
+
+@pytest.mark.parametrize("tag,shift", TAGS)
+def test_oracle_autograd_matches_reference_block(train_golden, tag, shift):
+    blk = _block(shift)
+    sd = {"b." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "attn_mask" not in k and "index" not in k)
+          for k, v in blk.state_dict().items()}
+    x = seeded_randn(700 + shift, 2, 196, 96).requires_grad_(True)
+    g = seeded_randn(710 + shift, 2, 196, 96)
+    y = O.swin_block(x, sd, "b", 14, 14, shift)
+    (y * g).sum().backward()
+    assert rel_err(y.detach(), train_golden[tag + "/y"]) < 2e-5
+    assert rel_err(x.grad, train_golden[tag + "/dx"]) < 5e-5
+    for name, _ in blk.named_parameters():
+        assert rel_err(sd["b." + name].grad, train_golden[f"{tag}/grad/{name}"]) < 5e-5, name
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,c", [(392, 96), (37, 128), (1000, 768), (5, 1024)])
+def test_hip_layernorm_bwd(rows, c):
+    from mumpy_hip import ops
+    x = (seeded_randn(1, rows, c) * 2 + 0.5).requires_grad_(True)
+    gm, bt = (1 + 0.1 * seeded_randn(2, c)).requires_grad_(True), (0.1 * seeded_randn(3, c)).requires_grad_(True)
+    dy = seeded_randn(4, rows, c)
+    F.layer_norm(x, (c,), gm, bt, 1e-5).backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5)
+    assert rel_err(dx.cpu(), x.grad) < 2e-5 and rel_err(dg.cpu(), gm.grad) < 2e-5 and rel_err(db.cpu(), bt.grad) < 2e-5
+    dx2, dg2, db2 = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)          # fixed-order reductions
+
+
+@pytest.mark.gpu
+def test_hip_gelu_fwd_bwd():
+    from mumpy_hip import ops
+    x = (seeded_randn(5, 4096) * 3).requires_grad_(True)
+    dy = seeded_randn(6, 4096)
+    y = F.gelu(x)
+    y.backward(dy)
+    assert rel_err(ops.gelu(x.detach().cuda()).cpu(), y.detach()) < 2e-6
+    assert rel_err(ops.gelu_bwd(x.detach().cuda(), dy.cuda()).cpu(), x.grad) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r,c", [(392, 96), (64, 64), (1, 7), (1000, 333)])
+def test_hip_transpose_and_col_sum(r, c):
+    from mumpy_hip import ops
+    x = seeded_randn(7, r, c)
+    assert torch.equal(ops.transpose(x.cuda()).cpu(), x.t().contiguous())
+    t32 = ops.transpose(x.cuda(), 32).cpu()
+    rp = (r + 31) // 32 * 32
+    assert t32.shape == (c, rp) and torch.equal(t32[:, :r], x.t()) and not t32[:, r:].any()
+    assert rel_err(ops.col_sum(x.cuda()).cpu(), x.double().sum(0).float()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(392, 288, 96), (100, 96, 384)])
+def test_hip_linear_backward(m, n, k):
+    from mumpy_hip.autograd import LinearFn
+    x, w, b = seeded_randn(8, m, k), seeded_randn(9, n, k) / k ** 0.5, seeded_randn(10, n)
+    dy = seeded_randn(11, m, n)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    F.linear(xr, wr, br).backward(dy)
+    xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    LinearFn.apply(xg, wg, bg).backward(dy.cuda())
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(wg.grad.cpu(), wr.grad) < 1e-5 and rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 3])
+@pytest.mark.parametrize("b,hs,w,c", [(2, 14, 14, 96), (1, 28, 14, 64), (3, 7, 7, 32)])
+def test_hip_window_attention_bwd_vs_oracle(b, hs, w, c, shift):
+    """qkv / bias-table gradients of the attention core against autograd on the oracle's window_attention."""
+    from models.modules.swinTransformer import relative_position_index
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import WindowAttentionFn
+    if min(hs, w) <= 7:
+        shift = 0
+    nh = c // 32
+    l = hs * w
+    qkv = seeded_randn(20, b, l, 3 * c)
+    table = seeded_randn(21, 169, nh) * 0.2
+    dout = seeded_randn(22, b, l, c)
+    idx = relative_position_index(7, 7)
+    mask = O.shift_attn_mask(hs, w, shift) if shift else None
+    # oracle: attention core on pre-computed qkv (identity qkv / proj weights would cost a GEMM; restate the core directly)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    out = O.window_attention_core(qr, tr, idx, hs, w, shift, mask)
+    out.backward(dout)
+    qg, tg = qkv.cuda().requires_grad_(True), table.cuda().requires_grad_(True)
+    tab, ids = ops.compact_attn_mask(mask.cuda()) if mask is not None else (None, None)
+    y = WindowAttentionFn.apply(qg, tg, idx.cuda(), (b, hs, w, c, shift, 32 ** -0.5), tab, ids)
+    assert rel_err(y.detach().cpu(), out.detach()) < 1e-5
+    y.backward(dout.cuda())
+    assert rel_err(qg.grad.cpu(), qr.grad) < 2e-5
+    assert rel_err(tg.grad.cpu(), tr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,shift", TAGS)
+def test_hip_swin_block_backward_matches_reference(train_golden, tag, shift):
+    from mumpy_hip.autograd import swin_block_train
+    blk = _block(shift).cuda()
+    x = seeded_randn(700 + shift, 2, 196, 96).cuda().requires_grad_(True)
+    g = seeded_randn(710 + shift, 2, 196, 96).cuda()
+    y = swin_block_train(blk, x)
+    (y * g).sum().backward()
+    assert rel_err(y.detach().cpu(), train_golden[tag + "/y"]) < 1e-4
+    assert rel_err(x.grad.cpu(), train_golden[tag + "/dx"]) < GRAD_TOL
+    for name, prm in blk.named_parameters():
+        assert prm.grad is not None, name
+        assert rel_err(prm.grad.cpu(), train_golden[f"{tag}/grad/{name}"]) < GRAD_TOL, name
