@@ -213,7 +213,7 @@ int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      void* stream);
 
 /* ---- backward kernels of the Swin block (rows 5-7 of 8a in training) ---------------------------------
- * LayerNorm backward (swin:266,305): x, dy, dx (rows,C); gamma, dgamma, dbeta (C); C % 4 == 0, C <= 1024.
+ * LayerNorm backward (swin:266,305): x, dy, dx (rows,C); gamma, dgamma, dbeta (C); C % 4 == 0, C <= 2048.
  * workspace: mumpy_layernorm_bwd_workspace_bytes(rows, C) bytes of device scratch.  Deterministic. */
 int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C);
 int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,

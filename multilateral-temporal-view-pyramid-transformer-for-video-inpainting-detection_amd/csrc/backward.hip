@@ -15,7 +15,7 @@ namespace {
 //   xhat = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 // dgamma / dbeta: each block accumulates its rows in registers (lane owns columns lane, lane+64, ...) and writes one
 // partial row per wave; ln_bwd_reduce_kernel sums the partials in order.
-constexpr int LN_MAXC4 = 4;             // float4 columns per lane: C <= 64 * 4 * 4 = 1024 (the widest LayerNorm on the path)
+constexpr int LN_MAXC4 = 8;             // float4 columns per lane: C <= 64 * 4 * 8 = 2048 (PatchMerging's LayerNorm(4C) at C = 512)
 
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
@@ -78,14 +78,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     }
 }
 
-// out[k][c] = sum_p partial[p][k][c] for k in {dgamma, dbeta}; also the generic fixed-order reduce of col_sum
-__global__ __launch_bounds__(256) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                             int64_t nparts, int64_t width, int64_t stride) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= width) return;
+// out[c] = sum_p partial[p * stride + c]: 64 columns per block, 16 lane groups each summing every 16th partial, combined
+// through LDS in group order -- a fixed summation tree (bitwise reproducible) without a thousands-long serial chain
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int64_t nparts, int64_t width, int64_t stride) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
     float s = 0.f;
-    for (int64_t p = 0; p < nparts; ++p) s += partial[p * stride + i];
-    out[i] = s;
+    if (i < width)
+        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * stride + i];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        out[i] = t;
+    }
 }
 
 // column sums of a (R, C) matrix: stage 1 writes one partial row per block of rows
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 
 static int64_t ln_bwd_waves(int64_t rows) {            // waves (= partial rows): enough to fill the chip, >= 8 rows each
     int64_t w = (rows + 7) / 8;
-    if (w > 4096) w = 4096;
+    if (w > 2048) w = 2048;
     if (w < 4) w = 4;
     return (w + 3) / 4 * 4;
 }
@@ -167,10 +177,10 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
                        rows, C, eps, rpw);
     MUMPY_CHECK_LAUNCH("layernorm_bwd");
     // partial rows are [dgamma(C) | dbeta(C)] per wave; dgamma and dbeta are separate caller buffers: two strided reduces
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), partial, dgamma,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, dgamma,
                        waves, (int64_t)C, (int64_t)2 * C);
     MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce dgamma)");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), partial + C, dbeta,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial + C, dbeta,
                        waves, (int64_t)C, (int64_t)2 * C);
     MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce dbeta)");
     return 0;
@@ -233,7 +243,7 @@ extern "C" int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, in
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nb), dim3(256), 0, as_stream(stream), x,
                        partial, R, C, rpb);
     MUMPY_CHECK_LAUNCH("col_sum(partial)");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, as_stream(stream), partial, out, nb,
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, out, nb,
                        (int64_t)C, (int64_t)C);
     MUMPY_CHECK_LAUNCH("col_sum(reduce)");
     return 0;

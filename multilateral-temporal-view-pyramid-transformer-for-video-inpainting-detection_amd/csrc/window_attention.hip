@@ -651,31 +651,41 @@ __global__ __launch_bounds__(256, 1) void win_attn_bwd_kv_kernel(BwdArgs a) {
     }
 }
 
-// dbias_full[head][i][j] = sum over that head's wave partials (fixed order); partial layout [it][jt][r][lane]
+// dbias_full[head][i][j] = sum over that head's wave partials (fixed order: 4 lane groups take every 4th partial, then
+// the groups are combined in order); partial layout [it][jt][r][lane]
 __global__ __launch_bounds__(256) void win_attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ full, int nH,
                                                                     int nblocks) {
+    __shared__ float red[4][64];
     const int head = blockIdx.y;
-    const int idx = blockIdx.x * 256 + threadIdx.x;                       // element of the 4096-float partial
-    if (idx >= 4096) return;
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + col;                                // element of the 4096-float partial
+    const int nparts = ((nblocks - head + nH - 1) / nH) * 4;             // this head's blocks x 4 waves
     float s = 0.f;
-    for (int blk = head; blk < nblocks; blk += nH)
-        for (int w = 0; w < 4; ++w) s += part[((int64_t)blk * 4 + w) * 4096 + idx];
+    for (int p = grp; p < nparts; p += 4) {
+        const int blk = head + (p >> 2) * nH, w = p & 3;
+        s += part[((int64_t)blk * 4 + w) * 4096 + idx];
+    }
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp) return;
+    s = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
     const int lane = idx & 63, r = (idx >> 6) & 15, jt = (idx >> 10) & 1, it = idx >> 11;
     const int i = 32 * it + (lane & 31), j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     full[(int64_t)head * 4096 + i * 64 + j] = s;
 }
 
-// dtable[t][head] = sum over the (i, j) pairs with relative_position_index[i][j] == t, in (i, j) order
-__global__ __launch_bounds__(256) void win_attn_dtable_kernel(const float* __restrict__ full, const int32_t* __restrict__ rel_index,
-                                                              float* __restrict__ dtable, int nH, int ntab) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const int head = blockIdx.y;
-    if (t >= ntab) return;
+// dtable[t][head] = sum over the (i, j) pairs with relative_position_index[i][j] == t: one wave per (t, head), lanes
+// stride over the 2401 pairs in order, then a fixed-order wave reduction
+__global__ __launch_bounds__(64) void win_attn_dtable_kernel(const float* __restrict__ full, const int32_t* __restrict__ rel_index,
+                                                             float* __restrict__ dtable, int nH, int ntab) {
+    const int t = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     float s = 0.f;
-    for (int i = 0; i < WT; ++i)
-        for (int j = 0; j < WT; ++j)
-            if (rel_index[i * WT + j] == t) s += full[(int64_t)head * 4096 + i * 64 + j];
-    dtable[(int64_t)t * nH + head] = s;
+    for (int p = lane; p < WT * WT; p += 64) {
+        const int i = p / WT, j = p - i * WT;
+        if (rel_index[p] == t) s += full[(int64_t)head * 4096 + i * 64 + j];
+    }
+    s = wave_sum(s, 64);
+    if (lane == 0) dtable[(int64_t)t * nH + head] = s;
 }
 
 }  // namespace
@@ -776,12 +786,12 @@ extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, c
     MUMPY_CHECK_LAUNCH("window_attention_bwd(q)");
     hipLaunchKernelGGL(win_attn_bwd_kv_kernel, dim3(grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(kv)");
-    hipLaunchKernelGGL(win_attn_dbias_reduce_kernel, dim3(16, a.nH), dim3(256), 0, as_stream(stream), a.dbias_part, full, a.nH,
+    hipLaunchKernelGGL(win_attn_dbias_reduce_kernel, dim3(64, a.nH), dim3(256), 0, as_stream(stream), a.dbias_part, full, a.nH,
                        (int)grid);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dbias reduce)");
     const int ntab = (2 * WS - 1) * (2 * WS - 1);
-    hipLaunchKernelGGL(win_attn_dtable_kernel, dim3((ntab + 255) / 256, a.nH), dim3(256), 0, as_stream(stream), full, rel_index, dtable,
-                       a.nH, ntab);
+    hipLaunchKernelGGL(win_attn_dtable_kernel, dim3(ntab, a.nH), dim3(64), 0, as_stream(stream), full, rel_index, dtable, a.nH,
+                       ntab);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dtable)");
     return 0;
 }

@@ -104,3 +104,47 @@ def swin_block_train(block, x):
     z = LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, block.mlp.fc1.weight, block.mlp.fc1.bias))
     return AddFn.apply(x, LinearFn.apply(hmid, block.mlp.fc2.weight, block.mlp.fc2.bias))
+
+
+def patch_merging_train(pm, x):
+    """PatchMerging.forward (swin:344-367) with a backward: 2x2 gather in the order (0,0),(1,0),(0,1),(1,1) (swin:357-361,
+    a pure permutation: torch indexing), LayerNorm(4C) and the bias-free reduction on the HIP kernels."""
+    h, w = pm.input_resolution
+    b, l, c = x.shape
+    g = x.view(b, h, w, c)
+    g = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], dim=-1).reshape(b, l // 4, 4 * c)
+    return LinearFn.apply(LayerNormFn.apply(g.contiguous(), pm.norm.weight, pm.norm.bias, pm.norm.eps), pm.reduction.weight, None)
+
+
+def baseline_tokenize_train(tok, x):
+    """BaselineTokenize.forward (swin:11-32) with a backward: the Conv3d with kernel = stride = (T,4,4) is a per-patch Linear
+    over (c, t, ky, kx); the patch gather is a reshape/permute, the product and the LayerNorm run on the HIP kernels.
+    K = 3*T*16 is zero-padded to a multiple of 32 for the GEMM (the pad columns carry no gradient)."""
+    w = tok.proj.weight                                        # (Cout, 3, T, 4, 4)
+    b, t, ch, hh, ww = x.shape
+    if t != w.shape[2]:
+        raise RuntimeError("BaselineTokenize expects the tubelet to span the whole clip (squeeze(-3), swin:29)")
+    p = w.shape[3]
+    cols = x.permute(0, 2, 1, 3, 4).reshape(b, ch, t, hh // p, p, ww // p, p).permute(0, 3, 5, 1, 2, 4, 6)
+    cols = cols.reshape(b * (hh // p) * (ww // p), ch * t * p * p)
+    k = cols.shape[1]
+    pad = (-k) % 32
+    cols = torch.nn.functional.pad(cols, (0, pad)).contiguous()
+    wmat = torch.nn.functional.pad(w.reshape(w.shape[0], k), (0, pad))
+    y = LinearFn.apply(cols, wmat, tok.proj.bias)
+    return LayerNormFn.apply(y, tok.norm.weight, tok.norm.bias, tok.norm.eps).reshape(b, -1, w.shape[0])
+
+
+def baseline_encoder_train(enc, x):
+    """BaselineEncoder.forward (encoder.py:22-30; SwinTransformer.forward_features swin:604-625) with a backward:
+    x (B,3,3,224,224) -> (B,1024,7,7).  Stochastic depth must be off (eval mode or drop_path_rate = 0)."""
+    m = enc.base
+    y = baseline_tokenize_train(m.patch_embed, x)
+    for layer in m.layers:
+        for blk in layer.blocks:
+            y = swin_block_train(blk, y)
+        if layer.downsample is not None:
+            y = patch_merging_train(layer.downsample, y)
+    y = LayerNormFn.apply(y, m.norm.weight, m.norm.bias, m.norm.eps)
+    b, _, c = y.shape
+    return y.reshape(b, 7, 7, c).permute(0, 3, 1, 2)

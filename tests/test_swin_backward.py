@@ -92,7 +92,7 @@ def test_hip_linear_backward(m, n, k):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shift", [0, 3])
-@pytest.mark.parametrize("b,hs,w,c", [(2, 14, 14, 96), (1, 28, 14, 64), (3, 7, 7, 32)])
+@pytest.mark.parametrize("b,hs,w,c", [(2, 14, 14, 96), (1, 28, 14, 64), (3, 7, 7, 32), (2, 280, 56, 128)])
 def test_hip_window_attention_bwd_vs_oracle(b, hs, w, c, shift):
     """qkv / bias-table gradients of the attention core against autograd on the oracle's window_attention."""
     from models.modules.swinTransformer import relative_position_index
@@ -134,3 +134,29 @@ def test_hip_swin_block_backward_matches_reference(train_golden, tag, shift):
     for name, prm in blk.named_parameters():
         assert prm.grad is not None, name
         assert rel_err(prm.grad.cpu(), train_golden[f"{tag}/grad/{name}"]) < GRAD_TOL, name
+
+
+@pytest.mark.gpu
+def test_hip_baseline_encoder_backward_vs_oracle():
+    """config 1's encoder (Swin-B, 24 blocks, 3 patch mergings, tokenizer): gradients of EVERY parameter and of the input
+    patches' consumer against torch autograd on the (reference-pinned) oracle, B=1."""
+    from models.encoder.encoder import BaselineEncoder
+    from mumpy_hip.autograd import baseline_encoder_train
+    enc = fill_module_(BaselineEncoder()).eval()
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "attn_mask" not in k else v)
+          for k, v in enc.state_dict().items()}
+    x = seeded_randn(800, 1, 3, 3, 224, 224)
+    g = seeded_randn(801, 1, 1024, 7, 7)
+    yo = O.baseline_encoder_forward(sd, x)
+    (yo * g).sum().backward()
+    enc = enc.cuda()
+    y = baseline_encoder_train(enc, x.cuda())
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 1e-4
+    worst = ("", 0.0)
+    for name, prm in enc.named_parameters():
+        assert prm.grad is not None, name
+        e = rel_err(prm.grad.cpu(), sd[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < 1e-3, worst

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Launch one kernel shape repeatedly (for rocprofv3 --pmc / timing).
   kernel_micro.py linear M N K [act]      | kernel_micro.py winattn B Hs W C shift | kernel_micro.py sample B Hs2 W C
+  | kernel_micro.py winattn_bwd B Hs W C shift | kernel_micro.py ln_bwd rows C
   | kernel_micro.py adamw N | kernel_micro.py maskloss B P | kernel_micro.py ln rows C"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +32,23 @@ elif op == "sample":
     x2 = torch.randn(b, hs2 * w, c, device=dev); pos = torch.rand(nw, 3, 49, 2, device=dev) * 2 - 1
     fn = lambda: ops.deform_sample(x2, pos, b, hs2, w, c, nw)
     work, unit = 4.0 * (2 * nw * 49 * c + nw * 3 * 49 * 2), "GB/s"
+if op == "winattn_bwd":
+    b, hs, w, c, shift = a
+    from models.modules.swinTransformer import build_shift_mask, relative_position_index
+    qkv = torch.randn(b, hs * w, 3 * c, device=dev); dout = torch.randn(b, hs * w, c, device=dev)
+    idx = relative_position_index(7, 7).to(dev)
+    bias = ops.expand_relpos_bias(torch.randn(169, c // 32, device=dev) * 0.2, idx)
+    idx32 = idx.to(torch.int32).reshape(-1).contiguous()
+    tab = ids = None
+    if shift:
+        tab, ids = ops.compact_attn_mask(build_shift_mask(hs, w, 7, shift).to(dev))
+    fn = lambda: ops.window_attention_bwd(qkv, dout, bias, idx32, b, hs, w, c, shift, 32 ** -0.5, tab, ids)
+    work, unit = 5 * 153664.0 * b * (hs // 7) * (w // 7) * (c // 32), "TFLOP/s"      # 5 products of 2*49*49*32 FLOP per unit
+if op == "ln_bwd":
+    rows, c = a
+    x = torch.randn(rows, c, device=dev); g = torch.ones(c, device=dev); dy = torch.randn(rows, c, device=dev)
+    fn = lambda: ops.layernorm_bwd(x, g, dy)
+    work, unit = 12.0 * rows * c, "GB/s"
 if op == "adamw":
     n, = a
     bufs = [torch.randn(n, device=dev) for _ in range(2)] + [torch.zeros(n, device=dev) for _ in range(2)]
