@@ -242,6 +242,17 @@ int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float*
                                void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C, int shift, float scale,
                                void* stream);
 
+/* GroupNorm (+ReLU) backward, NHWC (BaselineDecoder blocks, decoder.py:233-271): z, dy, dz (B,HW,C); stats_partial /
+ * nsplit_stats = the partial sums mumpy_gn_stats_nhwc_fwd produced for z; relu != 0 masks dy where GN(z) <= 0.
+ * dgamma, dbeta (C).  Same C / G limits as mumpy_gn_stats_nhwc_fwd.  Deterministic. */
+int64_t mumpy_gn_bwd_workspace_bytes(int B, int64_t HW, int C);
+int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_stats, const float* gamma, const float* beta,
+                      const float* dy, float* dz, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
+                      int B, int64_t HW, int C, int G, float eps, int relu, void* stream);
+
+/* backward of nn.Upsample(scale_factor=2, mode="bilinear", align_corners=...) on NHWC: dy (B,2H,2W,C) -> dx (B,H,W,C). */
+int mumpy_upsample2x_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

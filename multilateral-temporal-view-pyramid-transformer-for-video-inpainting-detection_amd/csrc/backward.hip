@@ -148,6 +148,161 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm (+ReLU) backward on NHWC (BaselineDecoder blocks, decoder.py:233-271).  With xhat = (z - mean_g) rstd_g,
+// pre = xhat gamma_c + beta_c, g = dy * [pre > 0] (ReLU) :
+//   dgamma_c = sum g xhat,  dbeta_c = sum g,  dz = rstd_g (g gamma_c - S1_g / n - xhat S2_g / n)
+//   S1_g = sum_{c in g} gamma_c T1[c],  S2_g = sum_{c in g} gamma_c T2[c],  T1[c] = sum_pixels g,  T2[c] = sum_pixels g xhat
+// pass 1 (grid (nsplit, B)): per-channel T1, T2 of its pixel range -> part[b][split][{T1,T2}][C]; pass 2: dz.
+// mean / rstd come from the forward's gn_stats partial sums (same layout, same fixed-order sum as the forward apply).
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ stats, int nsplit_s, int G, int b, int g, double n,
+                                               float eps, float& mean, float& rstd) {
+    double s = 0.0, q = 0.0;                                  // as in gn_apply_resample_kernel (decoder.hip): double, same order
+    for (int sp = 0; sp < nsplit_s; ++sp) {
+        const float* o = stats + (((int64_t)b * nsplit_s + sp) * G + g) * 2;
+        s += (double)o[0]; q += (double)o[1];
+    }
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                             const float* __restrict__ stats, int nsplit_s,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ part, int64_t HW, int C, int G, int nsplit,
+                                                             float eps, int relu) {
+    __shared__ float red[256][8];
+    __shared__ float gm[32], gr[32];
+    const int split = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lpp = C >> 2, ppi = 256 / lpp, c4 = tid % lpp, pl = tid / lpp;
+    const int cg = C / G;
+    if (tid < G) gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
+    __syncthreads();
+    const int64_t per = (HW + nsplit - 1) / nsplit;
+    const int64_t p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    if (pl < ppi) {
+        const int g = (4 * c4) / cg;
+        const float mean = gm[g], rstd = gr[g];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        const float* zb = z + (int64_t)b * HW * C + 4 * c4;
+        const float* db = dy + (int64_t)b * HW * C + 4 * c4;
+        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(zb + p * C) - mean) * rstd;
+            f32x4 d = *reinterpret_cast<const f32x4*>(db + p * C);
+            if (relu) {
+                const f32x4 pre = xh * ga + be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (!(pre[e] > 0.f)) d[e] = 0.f;
+            }
+            t1 += d;
+            t2 += d * xh;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid][e] = t1[e]; red[tid][4 + e] = t2[e]; }
+    __syncthreads();
+    if (tid < lpp) {                                          // fixed order over the pixel slots
+        f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+        for (int slot = 0; slot < ppi; ++slot)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a1[e] += red[slot * lpp + tid][e]; a2[e] += red[slot * lpp + tid][4 + e]; }
+        float* o = part + ((int64_t)b * nsplit + split) * 2 * C;
+        *reinterpret_cast<f32x4*>(o + 4 * tid) = a1;
+        *reinterpret_cast<f32x4*>(o + C + 4 * tid) = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, int nsplit_s,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ part, float* __restrict__ dz, int64_t HW, int C,
+                                                           int G, int nsplit, float eps, int relu) {
+    __shared__ float gm[32], gr[32], s1[32], s2[32];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / G;
+    if (tid < G) {
+        gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float* o = part + ((int64_t)b * nsplit + sp) * 2 * C;
+                t1 += o[c]; t2 += o[C + c];
+            }
+            a1 += gamma[c] * t1; a2 += gamma[c] * t2;
+        }
+        const float n = (float)HW * (float)cg;
+        s1[tid] = a1 / n; s2[tid] = a2 / n;
+    }
+    __syncthreads();
+    const int lpp = C >> 2;
+    const int64_t total = HW * lpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % lpp);
+        const int64_t p = i / lpp;
+        const int g = (4 * c4) / cg;
+        const float mean = gm[g], rstd = gr[g];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        const int64_t off = ((int64_t)b * HW + p) * C + 4 * c4;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + off) - mean) * rstd;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
+        if (relu) {
+            const f32x4 pre = xh * ga + be;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (!(pre[e] > 0.f)) d[e] = 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dz + off) = (d * ga - s1[g] - xh * s2[g]) * rstd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the bilinear x2 upsample (nn.Upsample(scale_factor=2, mode="bilinear"), NHWC): every input pixel gathers
+// from the output pixels that read it in the forward, with the forward's own index/weight function (deterministic).
+__device__ __forceinline__ void up_src(int o, int in, int out, int align, int& i0, int& i1, float& l0, float& l1) {
+    float src;
+    if (align) src = (out > 1) ? ((float)(in - 1) / (float)(out - 1)) * (float)o : 0.f;
+    else { src = 0.5f * ((float)o + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
+    i0 = (int)src;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                             int align) {
+    const int b = blockIdx.y;
+    const int lpp = C >> 2;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const int64_t total = (int64_t)H * W * lpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % lpp);
+        const int64_t p = i / lpp;
+        const int x = (int)(p % W), y = (int)(p / W);
+        f32x4 acc = {0, 0, 0, 0};
+        // candidate outputs: source coordinate within (y-1, y+1); 2y-2 .. 2y+3 covers both alignment modes
+        for (int oy = 2 * y - 2; oy <= 2 * y + 3; ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            int y0, y1; float ly0, ly1;
+            up_src(oy, H, Ho, align, y0, y1, ly0, ly1);
+            const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = 2 * x - 2; ox <= 2 * x + 3; ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                int x0, x1; float lx0, lx1;
+                up_src(ox, W, Wo, align, x0, x1, lx0, lx1);
+                const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                acc += *reinterpret_cast<const f32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + 4 * c4) * (wy * wx);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (((int64_t)b * H + y) * W + x) * C + 4 * c4) = acc;
+    }
+}
+
 }  // namespace
 
 static int64_t ln_bwd_waves(int64_t rows) {            // waves (= partial rows): enough to fill the chip, >= 8 rows each
@@ -246,5 +401,57 @@ extern "C" int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, in
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, out, nb,
                        (int64_t)C, (int64_t)C);
     MUMPY_CHECK_LAUNCH("col_sum(reduce)");
+    return 0;
+}
+
+static int gn_bwd_splits(int64_t HW, int C) {
+    int64_t s = (HW * C) / 65536;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int64_t mumpy_gn_bwd_workspace_bytes(int B, int64_t HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    return (int64_t)B * gn_bwd_splits(HW, C) * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_stats, const float* gamma,
+                                 const float* beta, const float* dy, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                 int64_t workspace_bytes, int B, int64_t HW, int C, int G, float eps, int relu, void* stream) {
+    MUMPY_REQUIRE(z && stats_partial && gamma && beta && dy && dz && dgamma && dbeta && workspace, MUMPY_ENULL, "gn_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(z) && aligned16(dy) && aligned16(dz) && aligned16(gamma) && aligned16(beta) && aligned16(workspace),
+                  MUMPY_EALIGN, "gn_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && HW > 0 && nsplit_stats > 0, MUMPY_EINVAL, "gn_bwd: bad sizes");
+    MUMPY_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && G > 0 && G <= 32 && C % G == 0 && (C / G) % 4 == 0, MUMPY_EINVAL,
+                  "gn_bwd: unsupported C=%d G=%d", C, G);
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_gn_bwd_workspace_bytes(B, HW, C), MUMPY_EINVAL, "gn_bwd: workspace too small");
+    const int ns = gn_bwd_splits(HW, C);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(ns, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial, nsplit_stats, gamma,
+                       beta, part, HW, C, G, ns, eps, relu);
+    MUMPY_CHECK_LAUNCH("gn_bwd(partial)");
+    int64_t grid = (HW * (C / 4) + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial,
+                       nsplit_stats, gamma, beta, part, dz, HW, C, G, ns, eps, relu);
+    MUMPY_CHECK_LAUNCH("gn_bwd(apply)");
+    // dbeta[c] = sum over (b, split) of T1, dgamma[c] of T2: partial rows are [T1(C) | T2(C)]
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part, dbeta,
+                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
+    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dbeta)");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part + C, dgamma,
+                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
+    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dgamma)");
+    return 0;
+}
+
+extern "C" int mumpy_upsample2x_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, void* stream) {
+    MUMPY_REQUIRE(dy && dx, MUMPY_ENULL, "upsample2x_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(dy) && aligned16(dx), MUMPY_EALIGN, "upsample2x_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MUMPY_EINVAL, "upsample2x_bwd: bad shape");
+    int64_t grid = ((int64_t)H * W * (C / 4) + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), dy, dx, H, W, C, align_corners);
+    MUMPY_CHECK_LAUNCH("upsample2x_bwd");
     return 0;
 }

@@ -4,6 +4,8 @@ import collections.abc
 import torch
 import torch.nn as nn
 
+from mumpy_hip.state import weights_epoch
+
 
 def to_2tuple(x):
     if isinstance(x, collections.abc.Iterable) and not isinstance(x, str):
@@ -52,14 +54,15 @@ class ConfigDict(dict):
 
 class Derived:
     """Cache of a tensor derived from parameters/buffers (transposed weights, expanded bias tables, compacted masks);
-    recomputed when any source's storage, version or device changes (load_state_dict, .cuda(), optimizer step)."""
+    recomputed when any source's storage, version or device changes (load_state_dict, .cuda(), a torch optimizer step) or
+    when a HIP kernel rewrote parameters in place (mumpy_hip.state.weights_epoch, bumped by FlatAdamW.step)."""
 
     def __init__(self):
         self._key = None
         self._val = None
 
     def get(self, sources, fn):
-        key = tuple((s.data_ptr(), s._version, str(s.device)) for s in sources)
+        key = (weights_epoch[0],) + tuple((s.data_ptr(), s._version, str(s.device)) for s in sources)
         if key != self._key:
             with torch.no_grad():
                 self._val = fn()

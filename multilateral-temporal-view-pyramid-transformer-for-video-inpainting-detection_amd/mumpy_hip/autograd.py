@@ -148,3 +148,105 @@ def baseline_encoder_train(enc, x):
     y = LayerNormFn.apply(y, m.norm.weight, m.norm.bias, m.norm.eps)
     b, _, c = y.shape
     return y.reshape(b, 7, 7, c).permute(0, 3, 1, 2)
+
+
+# ---------------------------------------------------------------------------------------------- BaselineDecoder (config 1)
+class Conv2dFn(torch.autograd.Function):
+    """3x3 / kxk same-padding convolution on NHWC (mumpy_conv2d_nhwc_fwd).  Backward:
+       dX = conv(dY, W flipped and transposed)  (the same implicit-GEMM kernel),
+       dW[tap] = dY^T X_shifted(tap)            (one GEMM per tap over the pixel dimension; the shifted copy of X is a
+                                                 zero-padded slice, i.e. data movement only),
+       db = column sums of dY."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, bias):
+        ctx.save_for_backward(x, w_krsc)
+        ctx.has_bias = bias is not None
+        return ops.conv2d_nhwc(x, w_krsc, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors                                   # x logical (B,Cin,H,W) NHWC; w (Cout,kh,kw,Cin)
+        cout, kh, kw, cin = w.shape
+        b, _, h, wd = x.shape
+        dy = dy.contiguous(memory_format=torch.channels_last)
+        dy2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)             # (P, Cout) view of the NHWC memory
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.conv2d_nhwc(dy, w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
+        if ctx.needs_input_grad[1]:
+            dyt = ops.transpose(dy2.contiguous(), 32)              # (Cout, Ppad)
+            xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, kw // 2, kw // 2, kh // 2, kh // 2))   # (B,H+2,W+2,Cin)
+            taps = []
+            for ky in range(kh):
+                for kx in range(kw):
+                    xs = xp[:, ky:ky + h, kx:kx + wd, :].reshape(-1, cin).contiguous()
+                    taps.append(ops.linear(dyt, ops.transpose(xs, 32)))                              # (Cout, Cin)
+            dw = torch.stack(taps, dim=1).reshape(cout, kh, kw, cin)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = ops.col_sum(dy2.contiguous())
+        return dx, dw, db
+
+
+class GroupNormReluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, groups, eps):
+        z, partial, nsplit = ops.gn_stats(z, groups)
+        ctx.save_for_backward(z, partial, gamma, beta)
+        ctx.cfg = (nsplit, groups, eps)
+        return ops.gn_apply_resample(z, (partial, nsplit, gamma, beta, groups, eps), act=ops.ACT_RELU)
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, partial, gamma, beta = ctx.saved_tensors
+        nsplit, groups, eps = ctx.cfg
+        dz, dg, db = ops.gn_bwd(z, (partial, nsplit), gamma, beta, dy, groups, eps, relu=True)
+        return dz, dg, db, None, None
+
+
+class Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, align_corners):
+        ctx.align = align_corners
+        return ops.gn_apply_resample(x, None, scale=2, align_corners=align_corners)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2x_bwd(dy, ctx.align), None
+
+
+class FinalConvFn(torch.autograd.Function):
+    """Conv2d(C -> 1, 3x3) (mumpy_final_conv_fwd).  Backward through the generic conv path with the single output channel
+    embedded in a 32-channel gradient image (the implicit-GEMM kernel wants channel counts in multiples of 32)."""
+
+    @staticmethod
+    def forward(ctx, x, w_krsc, bias):
+        ctx.save_for_backward(x, w_krsc)
+        return ops.final_conv(x, w_krsc, bias)
+
+    @staticmethod
+    def backward(ctx, dy):                                         # dy (B,1,H,W)
+        x, w = ctx.saved_tensors                                   # w (1,3,3,C)
+        b, c, h, wd = x.shape
+        dyp = torch.zeros(b, h, wd, 32, device=dy.device, dtype=torch.float32)
+        dyp[..., 0] = dy[:, 0]
+        wt = torch.zeros(c, 3, 3, 32, device=dy.device, dtype=torch.float32)
+        wt[..., 0] = w[0].permute(2, 0, 1).flip(1, 2)
+        dx = ops.conv2d_nhwc(dyp.permute(0, 3, 1, 2), wt)
+        dyt = ops.transpose(dy.reshape(-1, 1).contiguous(), 32)    # (1, Ppad)
+        xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, 1, 1, 1, 1))
+        taps = [ops.linear(dyt, ops.transpose(xp[:, ky:ky + h, kx:kx + wd, :].reshape(-1, c).contiguous(), 32))
+                for ky in range(3) for kx in range(3)]
+        dw = torch.stack(taps, dim=1).reshape(1, 3, 3, c)
+        return dx, dw, dy.sum().reshape(1)
+
+
+def baseline_decoder_train(dec, x):
+    """BaselineDecoder.forward (decoder.py:277-284) with a backward: x (B,in_channels,7,7) -> logits (B,1,224,224)."""
+    x = x.contiguous(memory_format=torch.channels_last)
+    for i in range(5):
+        conv, gn = getattr(dec, f"decoder_{i + 1}")[0], getattr(dec, f"decoder_{i + 1}")[1]
+        z = Conv2dFn.apply(x, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias)
+        a = GroupNormReluFn.apply(z, gn.weight, gn.bias, gn.num_groups, gn.eps)
+        x = Upsample2xFn.apply(a, True)
+    return FinalConvFn.apply(x, dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)

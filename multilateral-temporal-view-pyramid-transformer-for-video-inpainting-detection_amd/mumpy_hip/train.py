@@ -17,6 +17,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .state import bump_weights_epoch
 
 
 def split_param_groups(encoder: torch.nn.Module, decoder: torch.nn.Module) -> Dict[str, List[torch.nn.Parameter]]:
@@ -89,6 +90,7 @@ class FlatAdamW:
         self.steps += 1
         ops.adamw_step(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.steps, self.lr, self.betas, self.eps,
                        self.weight_decay, grad_scale)
+        bump_weights_epoch()              # weight-derived caches (models.modules.layers.Derived) must be rebuilt
 
     def scheduler_step(self, iter_max: int, power: float = 0.9, min_lr: float = 1e-5):
         self.sched_it += 1
