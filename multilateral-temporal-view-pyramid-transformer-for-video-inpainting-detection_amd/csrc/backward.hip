@@ -98,15 +98,20 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
     }
 }
 
-// column sums of a (R, C) matrix: stage 1 writes one partial row per block of rows
+// column sums of a (R, C) matrix: stage 1 writes one partial row per block of rows.  A block is 64 columns x 4 row lanes
+// (coalesced 256-B row segments, 4 rows in flight per column); the 4 row lanes are combined in order through LDS.
 __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t R,
                                                               int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 64 + col;
     float s = 0.f;
-    for (int64_t r = r0; r < r0 + rows_per_block && r < R; ++r) s += x[r * C + c];
-    partial[(int64_t)blockIdx.y * C + c] = s;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r0 + rows_per_block && r < R; r += 4) s += x[r * C + c];
+    red[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) partial[(int64_t)blockIdx.y * C + c] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
 }
 
 __device__ __forceinline__ float gelu_grad(float x) {          // d/dx [0.5 x (1 + erf(x / sqrt 2))]
@@ -376,9 +381,9 @@ extern "C" int mumpy_transpose_fwd(const float* in, float* out, int64_t R, int64
     return 0;
 }
 
-static int64_t col_sum_blocks(int64_t R) {
-    int64_t b = (R + 255) / 256;
-    if (b > 512) b = 512;
+static int64_t col_sum_blocks(int64_t R) {             // row blocks: >= 64 rows each, enough of them to fill the chip
+    int64_t b = (R + 63) / 64;
+    if (b > 2048) b = 2048;
     return b < 1 ? 1 : b;
 }
 
@@ -395,7 +400,7 @@ extern "C" int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, in
     const int64_t nb = col_sum_blocks(R);
     const int rpb = (int)((R + nb - 1) / nb);
     float* partial = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(col_sum_partial_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)nb), dim3(256), 0, as_stream(stream), x,
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)nb), dim3(256), 0, as_stream(stream), x,
                        partial, R, C, rpb);
     MUMPY_CHECK_LAUNCH("col_sum(partial)");
     hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, out, nb,
