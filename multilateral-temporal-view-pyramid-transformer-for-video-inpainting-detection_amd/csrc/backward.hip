@@ -135,6 +135,15 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const f32x4* __restrict__
     }
 }
 
+// out[b][i] = x[b][i] * scale[b]: stochastic depth (timm DropPath: per-sample Bernoulli mask / keep_prob); its own backward
+__global__ __launch_bounds__(256) void scale_samples_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale,
+                                                            f32x4* __restrict__ out, int64_t per4) {
+    const float sc = scale[blockIdx.y];
+    const f32x4* xb = x + (int64_t)blockIdx.y * per4;
+    f32x4* ob = out + (int64_t)blockIdx.y * per4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) ob[i] = xb[i] * sc;
+}
+
 // out (C, R) = in (R, C)^T, 64x64 tiles through LDS (stride 65: conflict-free both ways)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t R, int64_t C) {
     __shared__ float tile[64][65];
@@ -458,5 +467,19 @@ extern "C" int mumpy_upsample2x_bwd_nhwc(const float* dy, float* dx, int B, int 
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), dy, dx, H, W, C, align_corners);
     MUMPY_CHECK_LAUNCH("upsample2x_bwd");
+    return 0;
+}
+
+extern "C" int mumpy_scale_samples_fwd(const float* x, const float* scale, float* out, int B, int64_t per_sample, void* stream) {
+    if (B == 0 || per_sample == 0) return 0;
+    MUMPY_REQUIRE(x && scale && out, MUMPY_ENULL, "scale_samples: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(out) && per_sample % 4 == 0, MUMPY_EALIGN,
+                  "scale_samples: need 16-byte aligned buffers and per_sample %% 4 == 0");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && per_sample > 0, MUMPY_EINVAL, "scale_samples: bad shape");
+    int64_t grid = (per_sample / 4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(scale_samples_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const f32x4*>(x), scale, reinterpret_cast<f32x4*>(out), per_sample / 4);
+    MUMPY_CHECK_LAUNCH("scale_samples");
     return 0;
 }

@@ -18,7 +18,9 @@ def trunc_normal_(tensor, mean=0.0, std=1.0, a=-2.0, b=2.0):
 
 
 class DropPath(nn.Module):
-    """Stochastic depth.  Identity in eval mode, which is the only mode the HIP forward implements this round."""
+    """Stochastic depth.  Identity in eval mode (the inference forward).  The training path (mumpy_hip.autograd
+    .drop_path_train) reads `drop_prob` and applies the per-sample mask itself; calling this module in train mode with a
+    non-zero rate is refused so that a forward-only call cannot silently skip it."""
 
     def __init__(self, drop_prob: float = 0.0):
         super().__init__()
@@ -26,7 +28,8 @@ class DropPath(nn.Module):
 
     def forward(self, x):
         if self.training and self.drop_prob > 0.0:
-            raise NotImplementedError("training-mode forward (DropPath active) is SURVEY 8f-2; call .eval()")
+            raise NotImplementedError("the inference forward has no stochastic depth: call .eval(), or train through "
+                                      "mumpy_hip.autograd (swin_block_train / baseline_encoder_train)")
         return x
 
     def extra_repr(self):

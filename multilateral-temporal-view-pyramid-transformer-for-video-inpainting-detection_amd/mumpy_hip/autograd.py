@@ -6,7 +6,7 @@ bookkeeping only.  Linear backward reuses the forward GEMM (y = x W^T):
     dW = dY^T X    = linear(dY^T, X^T)         both operands transposed, token dim zero-padded to a multiple of 32
     db = column sums of dY (fixed-order two-stage reduction)
 `swin_block_train(block, x)` runs a `models.modules.swinTransformer.SwinTransformerBlock` through these Functions, with the
-same maths as its inference forward (swin:259-307; DropPath must be the identity, i.e. drop_path = 0 or eval mode).
+same maths as its inference forward (swin:259-307); in train mode stochastic depth draws a per-sample mask per branch.
 """
 import torch
 
@@ -67,6 +67,33 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+class DropPathFn(torch.autograd.Function):
+    """x[b] * scale[b] with scale = Bernoulli(keep)/keep per sample (timm's drop_path, swin:302,305)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.save_for_backward(scale)
+        return ops.scale_samples(x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (scale,) = ctx.saved_tensors
+        return ops.scale_samples(dy.contiguous(), scale), None
+
+
+def drop_path_train(module, x):
+    """The block's `drop_path` in training: identity for nn.Identity / eval mode / rate 0, else a fresh per-sample mask drawn
+    with torch's generator (as timm does: `x.new_empty(B).bernoulli_(keep)`), scaled by 1/keep."""
+    p = getattr(module, "drop_prob", 0.0)
+    if not module.training or p <= 0.0:
+        return x
+    keep = 1.0 - p
+    scale = torch.empty(x.shape[0], device=x.device, dtype=torch.float32).bernoulli_(keep)
+    if keep > 0.0:
+        scale.div_(keep)
+    return DropPathFn.apply(x, scale)
+
+
 class WindowAttentionFn(torch.autograd.Function):
     """softmax(q k^T * scale + bias + mask) v on raster-ordered qkv; differentiable in qkv and the bias table."""
 
@@ -89,8 +116,6 @@ class WindowAttentionFn(torch.autograd.Function):
 def swin_block_train(block, x):
     """SwinTransformerBlock.forward (swin:259-307) with a backward: x (B, L, C) -> (B, L, C), gradients reach x and every
     parameter of the block (norm1/2, qkv, relative_position_bias_table, proj, fc1, fc2)."""
-    if isinstance(block.drop_path, torch.nn.Module) and not isinstance(block.drop_path, torch.nn.Identity) and block.training:
-        raise NotImplementedError("swin_block_train: stochastic depth (DropPath > 0 in train mode) is not implemented")
     h, w = block.input_resolution
     b, l, c = x.shape
     hs = l // w
@@ -100,10 +125,10 @@ def swin_block_train(block, x):
     qkv = LinearFn.apply(y, att.qkv.weight, att.qkv.bias)
     a = WindowAttentionFn.apply(qkv, att.relative_position_bias_table, att.relative_position_index,
                                 (b, hs, w, block.dim, block.shift_size, att.scale), tab, ids)
-    x = AddFn.apply(x, LinearFn.apply(a, att.proj.weight, att.proj.bias))
+    x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
     z = LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, block.mlp.fc1.weight, block.mlp.fc1.bias))
-    return AddFn.apply(x, LinearFn.apply(hmid, block.mlp.fc2.weight, block.mlp.fc2.bias))
+    return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, block.mlp.fc2.weight, block.mlp.fc2.bias)))
 
 
 def patch_merging_train(pm, x):
@@ -137,7 +162,7 @@ def baseline_tokenize_train(tok, x):
 
 def baseline_encoder_train(enc, x):
     """BaselineEncoder.forward (encoder.py:22-30; SwinTransformer.forward_features swin:604-625) with a backward:
-    x (B,3,3,224,224) -> (B,1024,7,7).  Stochastic depth must be off (eval mode or drop_path_rate = 0)."""
+    x (B,3,3,224,224) -> (B,1024,7,7).  Stochastic depth is active when the module is in train mode."""
     m = enc.base
     y = baseline_tokenize_train(m.patch_embed, x)
     for layer in m.layers:

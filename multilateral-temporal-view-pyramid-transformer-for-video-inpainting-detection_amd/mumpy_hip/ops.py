@@ -496,3 +496,14 @@ def upsample2x_bwd(dy, align_corners=True):
     _call("mumpy_upsample2x_bwd_nhwc", _p(dy), _p(dx), b, ho // 2, wo // 2, c, 1 if align_corners else 0, _stream(),
           work=4.0 * (dy.numel() + dx.numel()))
     return dx
+
+
+def scale_samples(x, scale):
+    """out[b] = x[b] * scale[b] (stochastic depth); x (B, ...), scale (B,) on the GPU."""
+    x, scale = _chk(x, "x"), _chk(scale, "scale")
+    b = x.shape[0]
+    if scale.numel() != b:
+        raise RuntimeError("scale_samples: one scale per sample")
+    out = torch.empty_like(x)
+    _call("mumpy_scale_samples_fwd", _p(x), _p(scale), _p(out), b, x.numel() // b, _stream(), work=8.0 * x.numel())
+    return out

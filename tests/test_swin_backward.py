@@ -264,3 +264,31 @@ def test_hip_config1_training_steps_reduce_the_loss():
         z_inf = dec(enc(x))
         z_trn = baseline_decoder_train(dec, baseline_encoder_train(enc, x))
     assert rel_err(z_inf.cpu(), z_trn.cpu()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_drop_path_train_mode():
+    """Stochastic depth (swin:302,305): per-sample Bernoulli(keep)/keep scaling, identity in eval mode; the Function and its
+    backward against x * scale, and a Swin block in train mode drops whole residual branches per sample."""
+    from models.modules.layers import DropPath
+    from mumpy_hip.autograd import DropPathFn, drop_path_train, swin_block_train
+    x = seeded_randn(40, 6, 49, 32).cuda().requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25]).cuda()
+    y = DropPathFn.apply(x, scale)
+    assert torch.equal(y, x.detach() * scale.view(-1, 1, 1))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, scale.view(-1, 1, 1).expand_as(x))
+    dp = DropPath(0.5)
+    dp.eval()
+    assert drop_path_train(dp, x) is x
+    dp.train()
+    torch.manual_seed(0)
+    out = drop_path_train(dp, torch.ones(4096, 4, device="cuda"))
+    vals = set(out[:, 0].unique().tolist())
+    assert vals == {0.0, 2.0} and 0.4 < float((out[:, 0] > 0).float().mean()) < 0.6
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = fill_module_(SwinTransformerBlock(dim=32, input_resolution=(7, 7), num_heads=1, window_size=7, drop_path=0.999)).cuda()
+    blk.train()
+    xin = seeded_randn(41, 5, 49, 32).cuda()
+    torch.manual_seed(1)                                           # fixed generator state: the draw below is reproducible
+    assert torch.equal(swin_block_train(blk, xin), xin)            # keep = 0.001: both branches dropped for every sample
