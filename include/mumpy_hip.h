@@ -250,6 +250,10 @@ int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_sta
                       const float* dy, float* dz, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,
                       int B, int64_t HW, int C, int G, float eps, int relu, void* stream);
 
+/* backward of mumpy_temporal_attention_fwd (blocks:57-71 differentiated): qkv (S,T,3C), dout (S,T,C) -> dqkv (S,T,3C). */
+int mumpy_temporal_attention_bwd(const float* qkv, const float* dout, float* dqkv, int64_t S, int T, int C, int heads,
+                                 float scale, void* stream);
+
 /* stochastic depth (timm DropPath as used at swin:302,305): out[b][:] = x[b][:] * scale[b], scale = Bernoulli(keep)/keep
  * drawn by the caller; the backward is the same call on the gradient.  per_sample % 4 == 0. */
 int mumpy_scale_samples_fwd(const float* x, const float* scale, float* out, int B, int64_t per_sample, void* stream);

@@ -275,3 +275,30 @@ def baseline_decoder_train(dec, x):
         a = GroupNormReluFn.apply(z, gn.weight, gn.bias, gn.num_groups, gn.eps)
         x = Upsample2xFn.apply(a, True)
     return FinalConvFn.apply(x, dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)
+
+
+# ---------------------------------------------------------------------------------------------- global temporal blocks (row 13)
+class TemporalAttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, heads, scale):
+        s_, t, c3 = qkv.shape
+        ctx.save_for_backward(qkv)
+        ctx.cfg = (s_, t, c3 // 3, heads, scale)
+        return ops.temporal_attention(qkv, s_, t, c3 // 3, heads, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        return ops.temporal_attention_bwd(qkv, dout.contiguous(), *ctx.cfg), None, None
+
+
+def global_block_train(block, x):
+    """blocks.Block.forward (blocks:77-92) with a backward: x (S, T, C) sites x temporal tokens."""
+    att = block.attn.unwrapped
+    y = LayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    a = TemporalAttentionFn.apply(LinearFn.apply(y, att.qkv.weight, att.qkv.bias), att.heads, att.scale)
+    x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
+    z = LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
+    mlp = block.mlp.unwrapped
+    hmid = GeluFn.apply(LinearFn.apply(z, mlp.fc1.weight, mlp.fc1.bias))
+    return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, mlp.fc2.weight, mlp.fc2.bias)))

@@ -507,3 +507,10 @@ def scale_samples(x, scale):
     out = torch.empty_like(x)
     _call("mumpy_scale_samples_fwd", _p(x), _p(scale), _p(out), b, x.numel() // b, _stream(), work=8.0 * x.numel())
     return out
+
+
+def temporal_attention_bwd(qkv, dout, s_, t, c, heads, scale):
+    qkv, dout = _chk(qkv, "qkv"), _chk(dout, "dout")
+    dqkv = torch.empty_like(qkv)
+    _call("mumpy_temporal_attention_bwd", _p(qkv), _p(dout), _p(dqkv), s_, t, c, heads, scale, _stream(), work=4.0 * (2 * qkv.numel() + dout.numel()))
+    return dqkv

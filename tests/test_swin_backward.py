@@ -292,3 +292,27 @@ def test_hip_drop_path_train_mode():
     xin = seeded_randn(41, 5, 49, 32).cuda()
     torch.manual_seed(1)                                           # fixed generator state: the draw below is reproducible
     assert torch.equal(swin_block_train(blk, xin), xin)            # keep = 0.001: both branches dropped for every sample
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [1, 3, 5, 16])
+def test_hip_global_block_backward_vs_oracle(t):
+    """Global temporal ViT block (row 13): output, input gradient and every parameter gradient against autograd on the
+    oracle's global_block, S = 2*49 sites, T temporal tokens."""
+    from models.modules.blocks import Block
+    from mumpy_hip.autograd import global_block_train
+    blk = fill_module_(Block(dim=768, heads=12, mlp_dim=3072, dropout=0.0, drop_path=0.0)).eval()
+    sd = {"g." + k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    x = seeded_randn(50 + t, 98, t, 768)
+    g = seeded_randn(70 + t, 98, t, 768)
+    xo = x.clone().requires_grad_(True)
+    yo = O.global_block(xo, sd, "g", 12)
+    (yo * g).sum().backward()
+    blk = blk.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = global_block_train(blk, xg)
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 2e-5
+    assert rel_err(xg.grad.cpu(), xo.grad) < 1e-4
+    for name, prm in blk.named_parameters():
+        assert rel_err(prm.grad.cpu(), sd["g." + name].grad) < 1e-4, name
