@@ -243,7 +243,8 @@ int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float*
                                void* stream);
 
 /* GroupNorm (+ReLU) backward, NHWC (BaselineDecoder blocks, decoder.py:233-271): z, dy, dz (B,HW,C); stats_partial /
- * nsplit_stats = the partial sums mumpy_gn_stats_nhwc_fwd produced for z; relu != 0 masks dy where GN(z) <= 0.
+ * nsplit_stats = the partial sums mumpy_gn_stats_nhwc_fwd produced for z; `relu` is the activation that followed the
+ * norm: 0 none, 1 ReLU (dy masked where GN(z) <= 0), 2 sigmoid (dy scaled by s(1-s)).
  * dgamma, dbeta (C).  Same C / G limits as mumpy_gn_stats_nhwc_fwd.  Deterministic. */
 int64_t mumpy_gn_bwd_workspace_bytes(int B, int64_t HW, int C);
 int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_stats, const float* gamma, const float* beta,
@@ -258,8 +259,8 @@ int mumpy_temporal_attention_bwd(const float* qkv, const float* dout, float* dqk
  * drawn by the caller; the backward is the same call on the gradient.  per_sample % 4 == 0. */
 int mumpy_scale_samples_fwd(const float* x, const float* scale, float* out, int B, int64_t per_sample, void* stream);
 
-/* backward of nn.Upsample(scale_factor=2, mode="bilinear", align_corners=...) on NHWC: dy (B,2H,2W,C) -> dx (B,H,W,C). */
-int mumpy_upsample2x_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, void* stream);
+/* backward of nn.Upsample(scale_factor=s, mode="bilinear", align_corners=...) on NHWC, s in {2, 4}: dy (B,sH,sW,C) -> dx (B,H,W,C). */
+int mumpy_upsample_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int scale, int align_corners, void* stream);
 
 #ifdef __cplusplus
 }

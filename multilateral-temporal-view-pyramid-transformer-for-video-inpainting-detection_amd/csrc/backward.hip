@@ -207,10 +207,13 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
         for (int64_t p = p0 + pl; p < p1; p += ppi) {
             const f32x4 xh = (*reinterpret_cast<const f32x4*>(zb + p * C) - mean) * rstd;
             f32x4 d = *reinterpret_cast<const f32x4*>(db + p * C);
-            if (relu) {
+            if (relu) {                                       // act: 1 = ReLU mask, 2 = sigmoid'(pre) = s (1 - s)
                 const f32x4 pre = xh * ga + be;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) if (!(pre[e] > 0.f)) d[e] = 0.f;
+                for (int e = 0; e < 4; ++e) {
+                    if (relu == 1) { if (!(pre[e] > 0.f)) d[e] = 0.f; }
+                    else { const float sg = 1.0f / (1.0f + __expf(-pre[e])); d[e] *= sg * (1.0f - sg); }
+                }
             }
             t1 += d;
             t2 += d * xh;
@@ -267,47 +270,50 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
         if (relu) {
             const f32x4 pre = xh * ga + be;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) if (!(pre[e] > 0.f)) d[e] = 0.f;
+            for (int e = 0; e < 4; ++e) {
+                if (relu == 1) { if (!(pre[e] > 0.f)) d[e] = 0.f; }
+                else { const float sg = 1.0f / (1.0f + __expf(-pre[e])); d[e] *= sg * (1.0f - sg); }
+            }
         }
         *reinterpret_cast<f32x4*>(dz + off) = (d * ga - s1[g] - xh * s2[g]) * rstd;
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// backward of the bilinear x2 upsample (nn.Upsample(scale_factor=2, mode="bilinear"), NHWC): every input pixel gathers
+// backward of the bilinear x2 / x4 upsample (nn.Upsample(scale_factor=s, mode="bilinear"), NHWC): every input pixel gathers
 // from the output pixels that read it in the forward, with the forward's own index/weight function (deterministic).
-__device__ __forceinline__ void up_src(int o, int in, int out, int align, int& i0, int& i1, float& l0, float& l1) {
+__device__ __forceinline__ void up_src(int o, int in, int out, int scale, int align, int& i0, int& i1, float& l0, float& l1) {
     float src;
     if (align) src = (out > 1) ? ((float)(in - 1) / (float)(out - 1)) * (float)o : 0.f;
-    else { src = 0.5f * ((float)o + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
+    else { src = (1.0f / (float)scale) * ((float)o + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
     i0 = (int)src;
     i1 = i0 + ((i0 < in - 1) ? 1 : 0);
     l1 = src - (float)i0;
     l0 = 1.f - l1;
 }
 
-__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
-                                                             int align) {
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                           int scale, int align) {
     const int b = blockIdx.y;
     const int lpp = C >> 2;
-    const int Ho = 2 * H, Wo = 2 * W;
+    const int Ho = scale * H, Wo = scale * W;
     const int64_t total = (int64_t)H * W * lpp;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         const int c4 = (int)(i % lpp);
         const int64_t p = i / lpp;
         const int x = (int)(p % W), y = (int)(p / W);
         f32x4 acc = {0, 0, 0, 0};
-        // candidate outputs: source coordinate within (y-1, y+1); 2y-2 .. 2y+3 covers both alignment modes
-        for (int oy = 2 * y - 2; oy <= 2 * y + 3; ++oy) {
+        // candidate outputs: source coordinate within (y-1, y+1) -> o in [scale*(y-1) - scale, scale*(y+1) + scale]
+        for (int oy = scale * (y - 2); oy <= scale * (y + 2); ++oy) {
             if (oy < 0 || oy >= Ho) continue;
             int y0, y1; float ly0, ly1;
-            up_src(oy, H, Ho, align, y0, y1, ly0, ly1);
+            up_src(oy, H, Ho, scale, align, y0, y1, ly0, ly1);
             const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
             if (wy == 0.f) continue;
-            for (int ox = 2 * x - 2; ox <= 2 * x + 3; ++ox) {
+            for (int ox = scale * (x - 2); ox <= scale * (x + 2); ++ox) {
                 if (ox < 0 || ox >= Wo) continue;
                 int x0, x1; float lx0, lx1;
-                up_src(ox, W, Wo, align, x0, x1, lx0, lx1);
+                up_src(ox, W, Wo, scale, align, x0, x1, lx0, lx1);
                 const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
                 if (wx == 0.f) continue;
                 acc += *reinterpret_cast<const f32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + 4 * c4) * (wy * wx);
@@ -459,14 +465,17 @@ extern "C" int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int
     return 0;
 }
 
-extern "C" int mumpy_upsample2x_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int align_corners, void* stream) {
-    MUMPY_REQUIRE(dy && dx, MUMPY_ENULL, "upsample2x_bwd: null pointer");
-    MUMPY_REQUIRE(aligned16(dy) && aligned16(dx), MUMPY_EALIGN, "upsample2x_bwd: pointers must be 16-byte aligned");
-    MUMPY_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0, MUMPY_EINVAL, "upsample2x_bwd: bad shape");
+extern "C" int mumpy_upsample_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int scale, int align_corners,
+                                       void* stream) {
+    MUMPY_REQUIRE(dy && dx, MUMPY_ENULL, "upsample_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(dy) && aligned16(dx), MUMPY_EALIGN, "upsample_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (scale == 2 || scale == 4), MUMPY_EINVAL,
+                  "upsample_bwd: bad shape or scale %d", scale);
     int64_t grid = ((int64_t)H * W * (C / 4) + 255) / 256;
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), dy, dx, H, W, C, align_corners);
-    MUMPY_CHECK_LAUNCH("upsample2x_bwd");
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), dy, dx, H, W, C, scale,
+                       align_corners);
+    MUMPY_CHECK_LAUNCH("upsample_bwd");
     return 0;
 }
 

@@ -213,31 +213,47 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db
 
 
-class GroupNormReluFn(torch.autograd.Function):
+class GroupNormActFn(torch.autograd.Function):
+    """GroupNorm followed by act in {0, ops.ACT_RELU, ops.ACT_SIGMOID} on NHWC."""
+
     @staticmethod
-    def forward(ctx, z, gamma, beta, groups, eps):
+    def forward(ctx, z, gamma, beta, groups, eps, act):
         z, partial, nsplit = ops.gn_stats(z, groups)
         ctx.save_for_backward(z, partial, gamma, beta)
-        ctx.cfg = (nsplit, groups, eps)
-        return ops.gn_apply_resample(z, (partial, nsplit, gamma, beta, groups, eps), act=ops.ACT_RELU)
+        ctx.cfg = (nsplit, groups, eps, act)
+        return ops.gn_apply_resample(z, (partial, nsplit, gamma, beta, groups, eps), act=act)
 
     @staticmethod
     def backward(ctx, dy):
         z, partial, gamma, beta = ctx.saved_tensors
-        nsplit, groups, eps = ctx.cfg
-        dz, dg, db = ops.gn_bwd(z, (partial, nsplit), gamma, beta, dy, groups, eps, relu=True)
-        return dz, dg, db, None, None
+        nsplit, groups, eps, act = ctx.cfg
+        dz, dg, db = ops.gn_bwd(z, (partial, nsplit), gamma, beta, dy, groups, eps, act)
+        return dz, dg, db, None, None, None
 
 
-class Upsample2xFn(torch.autograd.Function):
+class GroupNormReluFn:
     @staticmethod
-    def forward(ctx, x, align_corners):
-        ctx.align = align_corners
-        return ops.gn_apply_resample(x, None, scale=2, align_corners=align_corners)
+    def apply(z, gamma, beta, groups, eps):
+        return GroupNormActFn.apply(z, gamma, beta, groups, eps, ops.ACT_RELU)
+
+
+class UpsampleFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=scale, mode="bilinear", align_corners=...) on NHWC, scale in {2, 4}."""
+
+    @staticmethod
+    def forward(ctx, x, scale, align_corners):
+        ctx.cfg = (scale, align_corners)
+        return ops.gn_apply_resample(x, None, scale=scale, align_corners=align_corners)
 
     @staticmethod
     def backward(ctx, dy):
-        return ops.upsample2x_bwd(dy, ctx.align), None
+        return ops.upsample_bwd(dy, *ctx.cfg), None, None
+
+
+class Upsample2xFn:
+    @staticmethod
+    def apply(x, align_corners):
+        return UpsampleFn.apply(x, 2, align_corners)
 
 
 class FinalConvFn(torch.autograd.Function):
@@ -302,3 +318,70 @@ def global_block_train(block, x):
     mlp = block.mlp.unwrapped
     hmid = GeluFn.apply(LinearFn.apply(z, mlp.fc1.weight, mlp.fc1.bias))
     return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, mlp.fc2.weight, mlp.fc2.bias)))
+
+
+# ---------------------------------------------------------------------------------------------- pyramid Decoder (row 15)
+def _conv_train(x, conv):
+    """nn.Conv2d (stride 1, same padding) through Conv2dFn; Cin is zero-padded to a multiple of 32 (the 9-channel DCT input)."""
+    w = conv.weight.permute(0, 2, 3, 1)                                   # (Cout, kh, kw, Cin)
+    pad = (-w.shape[3]) % 32
+    if pad:
+        w = torch.nn.functional.pad(w, (0, pad))
+        x = torch.cat([x, x.new_zeros(x.shape[0], pad, x.shape[2], x.shape[3])], dim=1)
+    return Conv2dFn.apply(x.contiguous(memory_format=torch.channels_last), w.contiguous(), conv.bias)
+
+
+def _gcm_train(m, x):
+    return _conv_train(_conv_train(x, m.conv_l1), m.conv_l2) + _conv_train(_conv_train(x, m.conv_r1), m.conv_r2)
+
+
+def decoder_train(dec, x, view_x, ffinfo):
+    """Decoder.forward (decoder.py:183-225) with a backward: x (B,2304,7,7), view_x[4][3] of (B,1,L,C), ffinfo (B,9,224,224)
+    -> (logits (B,1,224,224), feats (B,32,224,224)).  Convolutions, GroupNorm(+ReLU/Sigmoid), the bilinear resamplings and
+    the temporal heads (Conv3d with kernel = stride = (T,1,1), i.e. a per-pixel Linear over (C,T)) run on the HIP kernels
+    in both directions; the wiring in between (products, sums, concatenation, PixelShuffle, 2x2 average pooling) is left
+    to torch's own autograd in this first version."""
+    tdims = dec.input_token_temporal_dims
+    tmax = max(tdims)
+    rgb = []
+    for s_ in range(4):
+        seq = getattr(dec, f"rgb_decoder_{s_ + 1}")
+        conv, gn = seq[0], seq[1]
+        parts = []
+        for v, t in enumerate(view_x[s_]):                                # merge_views_along_channel_axis (decoder.py:43-53)
+            b, tt, n, c = t.shape
+            tv = tdims[v]
+            parts.append(t.reshape(b, tv, (tt * n) // tv, c).repeat(1, tmax // tv, 1, 1))
+        m = torch.cat(parts, dim=-1)                                      # (B, T, n, C')
+        b, t, n, c = m.shape
+        cols = m.permute(0, 2, 3, 1).reshape(b * n, c * t).contiguous()   # per pixel: features ordered (C', T) like the weight
+        y = LinearFn.apply(cols, conv.weight.reshape(conv.weight.shape[0], c * t), conv.bias)
+        side = dec.shape[s_]
+        y = y.reshape(b, side, side, -1).permute(0, 3, 1, 2)              # logical NCHW over NHWC memory
+        rgb.append(GroupNormActFn.apply(y, gn.weight, gn.bias, gn.num_groups, gn.eps, ops.ACT_RELU))
+    rgb1, rgb2, rgb3, rgb4 = rgb
+    freq, f = [], ffinfo
+    for i in range(5):
+        seq = getattr(dec, f"decoder_frequency_{i}")
+        z = _conv_train(torch.nn.functional.avg_pool2d(f, 2), seq[1])
+        f = GroupNormActFn.apply(z, seq[2].weight, seq[2].bias, seq[2].num_groups, seq[2].eps, ops.ACT_SIGMOID)
+        freq.append(f)
+    up = UpsampleFn.apply
+    out1 = torch.nn.functional.pixel_shuffle(_gcm_train(dec.gcm1, torch.cat([rgb4, x], 1)) * freq[4], 2)
+    gcn1 = _gcm_train(dec.gcm2, rgb3 * up(_conv_train(rgb4, dec.seb1.conv), 2, False))
+    gcn2 = _gcm_train(dec.gcm3, rgb2 * up(_conv_train(torch.cat([rgb3, up(rgb4, 2, False)], 1), dec.seb2.conv), 2, False))
+    gcn3 = _gcm_train(dec.gcm4, rgb1 * up(_conv_train(torch.cat([rgb2, up(rgb3, 2, False), up(rgb4, 4, False)], 1),
+                                                      dec.seb3.conv), 2, False))
+
+    def block(z, seq):
+        a = GroupNormActFn.apply(_conv_train(z, seq[0]), seq[1].weight, seq[1].bias, seq[1].num_groups, seq[1].eps, ops.ACT_RELU)
+        return up(a, 2, True)
+
+    z = block(gcn1 * freq[3] + out1, dec.decoder_2)
+    z = block(z + gcn2 * freq[2], dec.decoder_3)
+    z = block(z + gcn3 * freq[1], dec.decoder_4)
+    z = block(z * freq[0], dec.decoder_5)
+    feats = torch.nn.functional.avg_pool2d(torch.nn.functional.pixel_shuffle(z, 2), 2)
+    logits = FinalConvFn.apply(feats.contiguous(memory_format=torch.channels_last),
+                               dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)
+    return logits, feats

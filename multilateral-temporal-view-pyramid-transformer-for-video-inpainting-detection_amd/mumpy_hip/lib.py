@@ -51,7 +51,7 @@ SIGNATURES = {
     "mumpy_window_attention_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_gn_bwd_workspace_bytes": [c_i, c_l, c_i],
     "mumpy_gn_bwd_nhwc": [c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_i, c_i, c_fl, c_i, c_f],
-    "mumpy_upsample2x_bwd_nhwc": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_upsample_bwd_nhwc": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "mumpy_temporal_attention_bwd": [c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_scale_samples_fwd": [c_f, c_f, c_f, c_i, c_l, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],

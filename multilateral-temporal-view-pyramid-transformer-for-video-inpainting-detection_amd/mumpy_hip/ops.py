@@ -472,9 +472,9 @@ def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, s
     return dqkv, dtable
 
 
-def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, relu=True):
-    """GroupNorm(+ReLU) backward on NHWC: z, dy logical (B,C,H,W) with NHWC memory; stats = (partial, nsplit) from gn_stats(z).
-    -> (dz like z, dgamma, dbeta)."""
+def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, act=ACT_RELU):
+    """GroupNorm(+activation) backward on NHWC: z, dy logical (B,C,H,W) with NHWC memory; stats = (partial, nsplit) from
+    gn_stats(z); act = 0 / ACT_RELU / ACT_SIGMOID is the activation that followed the norm.  -> (dz like z, dgamma, dbeta)."""
     z, dy = _nhwc(z, "z"), _nhwc(dy, "dy")
     b, c, h, w = z.shape
     partial, nsplit = stats
@@ -484,18 +484,22 @@ def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, relu=True):
     wsb = int(_lib().mumpy_gn_bwd_workspace_bytes(b, h * w, c))
     ws = _ws(wsb, z.device)
     _call("mumpy_gn_bwd_nhwc", _p(z), _p(partial), nsplit, _p(_chk(gamma, "gamma")), _p(_chk(beta, "beta")), _p(dy), _p(dz), _p(dg),
-          _p(db), _p(ws), wsb, b, h * w, c, groups, eps, 1 if relu else 0, _stream(), work=20.0 * z.numel())
+          _p(db), _p(ws), wsb, b, h * w, c, groups, eps, int(act), _stream(), work=20.0 * z.numel())
     return dz, dg, db
 
 
-def upsample2x_bwd(dy, align_corners=True):
-    """dy logical (B,C,2H,2W) NHWC -> dx (B,C,H,W) NHWC: backward of the bilinear x2 upsample."""
+def upsample_bwd(dy, scale=2, align_corners=True):
+    """dy logical (B,C,sH,sW) NHWC -> dx (B,C,H,W) NHWC: backward of the bilinear x2 / x4 upsample."""
     dy = _nhwc(dy, "dy")
     b, c, ho, wo = dy.shape
-    dx = empty_nhwc(b, c, ho // 2, wo // 2, dy.device)
-    _call("mumpy_upsample2x_bwd_nhwc", _p(dy), _p(dx), b, ho // 2, wo // 2, c, 1 if align_corners else 0, _stream(),
+    dx = empty_nhwc(b, c, ho // scale, wo // scale, dy.device)
+    _call("mumpy_upsample_bwd_nhwc", _p(dy), _p(dx), b, ho // scale, wo // scale, c, scale, 1 if align_corners else 0, _stream(),
           work=4.0 * (dy.numel() + dx.numel()))
     return dx
+
+
+def upsample2x_bwd(dy, align_corners=True):
+    return upsample_bwd(dy, 2, align_corners)
 
 
 def scale_samples(x, scale):

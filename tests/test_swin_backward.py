@@ -316,3 +316,61 @@ def test_hip_global_block_backward_vs_oracle(t):
     assert rel_err(xg.grad.cpu(), xo.grad) < 1e-4
     for name, prm in blk.named_parameters():
         assert rel_err(prm.grad.cpu(), sd["g." + name].grad) < 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,align", [(2, False), (4, False), (2, True)])
+def test_hip_upsample_bwd_scales(scale, align):
+    from mumpy_hip import ops
+    x = seeded_randn(60, 2, 32, 7, 7).requires_grad_(True)
+    dy = seeded_randn(61, 2, 32, 7 * scale, 7 * scale)
+    F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align).backward(dy)
+    dx = ops.upsample_bwd(dy.cuda().contiguous(memory_format=torch.channels_last), scale, align)
+    assert rel_err(dx.cpu(), x.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_groupnorm_sigmoid_bwd():
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import GroupNormActFn
+    z, gm, bt = seeded_randn(62, 2, 128, 14, 14) * 2, 1 + 0.1 * seeded_randn(63, 128), 0.1 * seeded_randn(64, 128)
+    dy = seeded_randn(65, 2, 128, 14, 14)
+    zr, gr, br = [t.clone().requires_grad_(True) for t in (z, gm, bt)]
+    torch.sigmoid(F.group_norm(zr, 8, gr, br, 1e-5)).backward(dy)
+    zg = z.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gg, bg = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    GroupNormActFn.apply(zg, gg, bg, 8, 1e-5, ops.ACT_SIGMOID).backward(dy.cuda())
+    assert rel_err(zg.grad.cpu(), zr.grad) < 5e-5 and rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+@pytest.mark.gpu
+def test_hip_pyramid_decoder_backward_vs_oracle():
+    """The multi-pyramid Decoder (row 15) at B=1, T=3: logits, features and every parameter gradient, plus the gradients
+    flowing back into the encoder outputs (final tokens, the 12 view tensors, the DCT features), against the oracle."""
+    from models.decoder.decoder import Decoder
+    from mumpy_hip.autograd import decoder_train
+    dec = fill_module_(Decoder()).eval()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    chans = [(96, 96, 128), (192, 192, 256), (384, 384, 512), (768, 768, 1024)]
+    lens = [3136, 784, 196, 49]
+    x = seeded_randn(900, 1, 2304, 7, 7)
+    vx = [[seeded_randn(901 + 10 * s + v, 1, 1, lens[s] * (3 if v == 2 else 1), chans[s][v]) for v in range(3)] for s in range(4)]
+    ff = seeded_randn(950, 1, 9, 224, 224)
+    g = seeded_randn(951, 1, 1, 224, 224)
+    leaves_o = [x.clone().requires_grad_(True), [[t.clone().requires_grad_(True) for t in st] for st in vx], ff.clone().requires_grad_(True)]
+    lo, fo = O.decoder_forward(sd, leaves_o[0], leaves_o[1], leaves_o[2], [1, 1, 3])
+    (lo * g).sum().backward()
+    dec = dec.cuda()
+    leaves_g = [x.cuda().requires_grad_(True), [[t.cuda().requires_grad_(True) for t in st] for st in vx], ff.cuda().requires_grad_(True)]
+    lg, fg = decoder_train(dec, leaves_g[0], leaves_g[1], leaves_g[2])
+    (lg * g.cuda()).sum().backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 2e-4 and rel_err(fg.detach().cpu(), fo.detach()) < 2e-4
+    tol = 3e-3                                                  # ReLU / sigmoid chains over ~10 stages (see the baseline decoder test)
+    assert rel_err(leaves_g[0].grad.cpu(), leaves_o[0].grad) < tol
+    assert rel_err(leaves_g[2].grad.cpu(), leaves_o[2].grad) < tol
+    for s in range(4):
+        for v in range(3):
+            assert rel_err(leaves_g[1][s][v].grad.cpu(), leaves_o[1][s][v].grad) < tol, (s, v)
+    for name, prm in dec.named_parameters():
+        assert prm.grad is not None, name
+        assert rel_err(prm.grad.cpu(), sd[name].grad) < tol, name
