@@ -262,6 +262,21 @@ int mumpy_scale_samples_fwd(const float* x, const float* scale, float* out, int 
 /* backward of nn.Upsample(scale_factor=s, mode="bilinear", align_corners=...) on NHWC, s in {2, 4}: dy (B,sH,sW,C) -> dx (B,H,W,C). */
 int mumpy_upsample_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int scale, int align_corners, void* stream);
 
+/* ---- training kernels of the deformable cross-view attention (row 10; deform:324-405) -------------------------------
+ * depthwise 5x5 convolution (padding 2) inside 7x7 windows, the first layer of `conv_offset` (deform:228-233):
+ * x, u, du, dx (N, 49, C) token-major windows; w (C, 25) = the module's (C,1,5,5) weight; b (C).  The backward writes dx,
+ * dw as a (25, C) image (tap-major: transpose to get (C,25)) and db (C).  C <= 384. */
+int mumpy_dwconv5_window_fwd(const float* x, const float* w, const float* b, float* u, int64_t N, int C, void* stream);
+int64_t mumpy_dwconv5_window_bwd_workspace_bytes(int64_t N, int C);
+int mumpy_dwconv5_window_bwd(const float* x, const float* w, const float* du, float* dx, float* dw, float* db,
+                             void* workspace, int64_t workspace_bytes, int64_t N, int C, void* stream);
+
+/* backward of mumpy_deform_sample_fwd in window form (every kv window its own 7x7 image): x2, dsampled, dx2 (B2,49,C),
+ * pos (nq,3,49,2); kv window b2 uses pos[b2 % nq].  dpos_part (B2,3,49,2) holds each kv window's contribution; the
+ * caller sums the B2/nq windows that share a q window. */
+int mumpy_deform_sample_bwd(const float* x2, const float* pos, const float* dsampled, float* dx2, float* dpos_part,
+                            int64_t B2, int C, int nq, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -385,3 +385,37 @@ def decoder_train(dec, x, view_x, ffinfo):
     logits = FinalConvFn.apply(feats.contiguous(memory_format=torch.channels_last),
                                dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)
     return logits, feats
+
+
+# ---------------------------------------------------------------------------------------------- SwinDAttention (row 10)
+class DWConv5Fn(torch.autograd.Function):
+    """Depthwise 5x5 conv (padding 2) inside 7x7 windows: x (N,49,C) token-major, weight (C,1,5,5), bias (C)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        w25 = weight.reshape(weight.shape[0], 25).contiguous()
+        ctx.save_for_backward(x, w25)
+        ctx.wshape = weight.shape
+        return ops.dwconv5_window(x, w25, bias)
+
+    @staticmethod
+    def backward(ctx, du):
+        x, w25 = ctx.saved_tensors
+        dx, dw, db = ops.dwconv5_window_bwd(x, w25, du.contiguous())
+        return dx, dw.reshape(ctx.wshape), db
+
+
+class DeformSampleFn(torch.autograd.Function):
+    """Bilinear sampling of kv windows at the learned positions (grid_sample semantics of deform:353-356), window form:
+    x2w (B2,49,C), pos (nq,3,49,2) -> (B2,49,C); kv window b2 uses pos[b2 % nq]."""
+
+    @staticmethod
+    def forward(ctx, x2w, pos):
+        ctx.save_for_backward(x2w, pos)
+        b2, _, c = x2w.shape
+        return ops.deform_sample(x2w.reshape(b2, 49, c), pos, b2, 7, 7, c, pos.shape[0])
+
+    @staticmethod
+    def backward(ctx, ds):
+        x2w, pos = ctx.saved_tensors
+        return ops.deform_sample_bwd(x2w, pos, ds.contiguous())

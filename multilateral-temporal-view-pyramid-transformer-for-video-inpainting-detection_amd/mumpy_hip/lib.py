@@ -54,6 +54,10 @@ SIGNATURES = {
     "mumpy_upsample_bwd_nhwc": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "mumpy_temporal_attention_bwd": [c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_scale_samples_fwd": [c_f, c_f, c_f, c_i, c_l, c_f],
+    "mumpy_dwconv5_window_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f],
+    "mumpy_dwconv5_window_bwd_workspace_bytes": [c_l, c_i],
+    "mumpy_dwconv5_window_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_f],
+    "mumpy_deform_sample_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }
 ABI_VERSION = 1

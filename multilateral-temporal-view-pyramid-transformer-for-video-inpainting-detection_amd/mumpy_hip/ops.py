@@ -518,3 +518,39 @@ def temporal_attention_bwd(qkv, dout, s_, t, c, heads, scale):
     dqkv = torch.empty_like(qkv)
     _call("mumpy_temporal_attention_bwd", _p(qkv), _p(dout), _p(dqkv), s_, t, c, heads, scale, _stream(), work=4.0 * (2 * qkv.numel() + dout.numel()))
     return dqkv
+
+
+# ------------------------------------------------------------------------------- deformable attention, training (row 10)
+def dwconv5_window(x, w25, b):
+    """x (N,49,C) token-major windows, w25 (C,25), b (C) -> (N,49,C): depthwise 5x5 conv (padding 2) inside each 7x7 window."""
+    x = _chk(x, "x")
+    n, _, c = x.shape
+    u = torch.empty_like(x)
+    _call("mumpy_dwconv5_window_fwd", _p(x), _p(_chk(w25, "w")), _p(_chk(b, "b")), _p(u), n, c, _stream(), work=8.0 * x.numel())
+    return u
+
+
+def dwconv5_window_bwd(x, w25, du):
+    """-> (dx (N,49,C), dw (C,25), db (C))."""
+    x, du = _chk(x, "x"), _chk(du, "du")
+    n, _, c = x.shape
+    dx = torch.empty_like(x)
+    dw_t = torch.empty(26, c, device=x.device, dtype=torch.float32)       # rows 0..24 = taps; row 25 unused scratch
+    db = torch.empty(c, device=x.device, dtype=torch.float32)
+    wsb = int(_lib().mumpy_dwconv5_window_bwd_workspace_bytes(n, c))
+    ws = _ws(wsb, x.device)
+    _call("mumpy_dwconv5_window_bwd", _p(x), _p(_chk(w25, "w")), _p(du), _p(dx), _p(dw_t), _p(db), _p(ws), wsb, n, c, _stream(),
+          work=16.0 * x.numel())
+    return dx, transpose(dw_t[:25].contiguous()), db
+
+
+def deform_sample_bwd(x2w, pos, dsampled):
+    """window form: x2w, dsampled (B2,49,C), pos (nq,3,49,2) -> (dx2 (B2,49,C), dpos (nq,3,49,2))."""
+    x2w, pos, dsampled = _chk(x2w, "x2"), _chk(pos, "pos"), _chk(dsampled, "dsampled")
+    b2, _, c = x2w.shape
+    nq = pos.shape[0]
+    dx2 = torch.empty_like(x2w)
+    part = torch.empty(b2, 3, 49, 2, device=x2w.device, dtype=torch.float32)
+    _call("mumpy_deform_sample_bwd", _p(x2w), _p(pos), _p(dsampled), _p(dx2), _p(part), b2, c, nq, _stream(), work=12.0 * x2w.numel())
+    # kv windows qw + m*nq share q window qw: a (r, nq, ...) view summed over r (a few KB: left to torch)
+    return dx2, part.view(b2 // nq, nq, 3, 49, 2).sum(0)

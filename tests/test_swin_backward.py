@@ -374,3 +374,39 @@ def test_hip_pyramid_decoder_backward_vs_oracle():
     for name, prm in dec.named_parameters():
         assert prm.grad is not None, name
         assert rel_err(prm.grad.cpu(), sd[name].grad) < tol, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c", [(6, 32), (3, 256), (5, 64)])
+def test_hip_dwconv5_window_fwd_bwd(n, c):
+    """first layer of conv_offset (deform:228): depthwise 5x5, padding 2, inside 7x7 windows."""
+    from mumpy_hip.autograd import DWConv5Fn
+    x, w, b, du = seeded_randn(100, n, 49, c), seeded_randn(101, c, 1, 5, 5) / 5, seeded_randn(102, c), seeded_randn(103, n, 49, c)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = F.conv2d(xr.reshape(n, 7, 7, c).permute(0, 3, 1, 2), wr, br, padding=2, groups=c).permute(0, 2, 3, 1).reshape(n, 49, c)
+    ref.backward(du)
+    xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    u = DWConv5Fn.apply(xg, wg, bg)
+    u.backward(du.cuda())
+    assert rel_err(u.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(wg.grad.cpu(), wr.grad) < 1e-5 and rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,r,c", [(4, 1, 96), (2, 3, 192), (1, 5, 96), (3, 1, 768)])
+def test_hip_deform_sample_bwd(nq, r, c):
+    """grid_sample backward (deform:353-356) wrt the kv windows and the sampling positions, incl. points outside the window."""
+    from mumpy_hip.autograd import DeformSampleFn
+    b2 = nq * r
+    x2 = seeded_randn(110, b2, 49, c)
+    pos = (seeded_randn(111, nq, 3, 49, 2) * 0.7).clamp(-1.3, 1.3)          # some points fall outside [-1, 1]: zeros padding
+    ds = seeded_randn(112, b2, 49, c)
+    xr, pr = x2.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    ref = O.bilinear_sample_window(xr, pr[torch.arange(b2) % nq])
+    ref.backward(ds)
+    xg, pg = x2.cuda().requires_grad_(True), pos.cuda().requires_grad_(True)
+    out = DeformSampleFn.apply(xg, pg)
+    out.backward(ds.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5
+    assert rel_err(pg.grad.cpu(), pr.grad) < 5e-5
