@@ -271,6 +271,13 @@ int64_t mumpy_dwconv5_window_bwd_workspace_bytes(int64_t N, int C);
 int mumpy_dwconv5_window_bwd(const float* x, const float* w, const float* du, float* dx, float* dw, float* db,
                              void* workspace, int64_t workspace_bytes, int64_t N, int C, void* stream);
 
+/* backward of mumpy_deform_attention_fwd in window form (deform:360-395): q (B1w,49,C), kv (B1w*r,49,2C), dout (B1w,49,C).
+ * dq_part (B1w*r,49,C): the contribution of each kv window to its q window (b2 % B1w) -- the caller sums the r members;
+ * dkv (B1w*r,49,2C).  workspace from the _bytes query. */
+int64_t mumpy_deform_attention_bwd_workspace_bytes(int64_t B2w, int C);
+int mumpy_deform_attention_bwd(const float* q, const float* kv, const float* dout, float* dq_part, float* dkv, void* workspace,
+                               int64_t workspace_bytes, int64_t B1w, int r, int C, float scale, void* stream);
+
 /* backward of mumpy_deform_sample_fwd in window form (every kv window its own 7x7 image): x2, dsampled, dx2 (B2,49,C),
  * pos (nq,3,49,2); kv window b2 uses pos[b2 % nq].  dpos_part (B2,3,49,2) holds each kv window's contribution; the
  * caller sums the B2/nq windows that share a q window. */

@@ -651,6 +651,180 @@ __global__ __launch_bounds__(256, 1) void win_attn_bwd_kv_kernel(BwdArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the deformable cross-view attention core (deform:360-395 in window form): unit = (kv window b2, head);
+// q from q window b2 % B1w (x1.repeat, deform:330), k/v from kv[b2], dO from output window b2 / r (the r-tuple sum,
+// deform:394-395, hands the same dO to its r members).  Same two-orientation scheme as the self-attention backward;
+// no bias (only the 49 -> 64 key padding), scale on the product.  dq_part holds each kv window's contribution to its q
+// window; the caller sums the r contributions per q window.
+struct CrossBwdArgs {
+    const float* q; const float* kv; const float* dout;
+    float* dq_part; float* dkv; float* stats;
+    int C, nH, r, B1w;
+    float scale;
+    int64_t units;
+};
+
+__device__ __forceinline__ f32x4 pad_bias(int jt, int g, int h) {       // 0 on real keys, -1e30 on key 52 (keys 49..51 / 53.. are skipped)
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (jt == 1 && g == 2 && h) bv.x = -1e30f;
+    return bv;
+}
+
+__global__ __launch_bounds__(256, 1) void deform_attn_bwd_q_kernel(CrossBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= a.units) return;
+    const int head = (int)(u % a.nH);
+    const int64_t b2 = u / a.nH;
+    const int64_t qw = b2 % a.B1w, b1 = b2 / a.r;
+    const uint32_t rq = 4u * a.C, rk = 8u * a.C;                          // row pitches in bytes
+    const char* qb = reinterpret_cast<const char*>(a.q + qw * WT * a.C + head * HD);
+    const char* kb = reinterpret_cast<const char*>(a.kv + b2 * WT * 2 * a.C + head * HD);
+    const char* vb = kb + 4 * a.C;
+    const char* dob = reinterpret_cast<const char*>(a.dout + b1 * WT * a.C + head * HD);
+    auto row = [](int p) { return (uint32_t)(p < WT ? p : WT - 1); };     // padded slots re-read row 48
+    f32x4 qf[2][4], kf[2][4], vkf[2][4], dof[2][4];
+    float kv[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t p = row(32 * t + c);
+        load_frag16(qf[t], qb, p * rq + 64u * h);
+        load_frag16(kf[t], kb, p * rk + 64u * h);
+        load_frag16(vkf[t], vb, p * rk + 64u * h);
+        load_frag16(dof[t], dob, p * rq + 64u * h);
+    }
+    for_pv_steps([&](int jt, int g, int e) {
+        kv[jt][4 * g + e] = *reinterpret_cast<const float*>(kb + (row(32 * jt + 8 * g + 4 * h + e) * rk + 4u * c));
+    });
+    char* dqb = reinterpret_cast<char*>(a.dq_part + b2 * WT * a.C + head * HD);
+    float* st = a.stats + u * 192;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[jt][r] = 0.f; dp[jt][r] = 0.f; }
+        qk_product(s, kf, qf[it]);
+        const int qi = 32 * it + c;
+        float m, inv;
+        bias_softmax<false>(s, [&](int jt, int g) { return pad_bias(jt, g, h); }, nullptr, qi, h, a.scale, &m, &inv);
+        qk_product(dp, vkf, dof[it]);
+        float d = 0.f;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (jt == 1 && r >= 9) continue;
+                d += s[jt][r] * dp[jt][r];
+            }
+        d += __shfl_xor(d, 32);
+        const bool qvalid = qi < WT;
+#pragma unroll
+        for (int jt = 0; jt < 2; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (jt == 1 && r >= 9) { s[jt][r] = 0.f; continue; }
+                s[jt][r] = qvalid ? s[jt][r] * (dp[jt][r] - d) : 0.f;
+            }
+        if (h == 0 && qvalid) { st[qi] = m; st[64 + qi] = inv; st[128 + qi] = d; }
+        f32x16 o;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] = 0.f;
+        pv_product(o, s, kv);                                             // dQ = dS K
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;
+            const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (i < WT) *reinterpret_cast<float*>(dqb + ((uint32_t)i * rq + 4u * c)) = o[r] * a.scale;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void deform_attn_bwd_kv_kernel(CrossBwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= a.units) return;
+    const int head = (int)(u % a.nH);
+    const int64_t b2 = u / a.nH;
+    const int64_t qw = b2 % a.B1w, b1 = b2 / a.r;
+    const uint32_t rq = 4u * a.C, rk = 8u * a.C;
+    const char* qb = reinterpret_cast<const char*>(a.q + qw * WT * a.C + head * HD);
+    const char* kb = reinterpret_cast<const char*>(a.kv + b2 * WT * 2 * a.C + head * HD);
+    const char* vb = kb + 4 * a.C;
+    const char* dob = reinterpret_cast<const char*>(a.dout + b1 * WT * a.C + head * HD);
+    auto row = [](int p) { return (uint32_t)(p < WT ? p : WT - 1); };
+    f32x4 qf[2][4], kf[2][4], vkf[2][4], dof[2][4];
+    float qv[2][16], dov[2][16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t p = row(32 * t + c);
+        load_frag16(qf[t], qb, p * rq + 64u * h);
+        load_frag16(kf[t], kb, p * rk + 64u * h);
+        load_frag16(vkf[t], vb, p * rk + 64u * h);
+        load_frag16(dof[t], dob, p * rq + 64u * h);
+    }
+    for_pv_steps([&](int it, int g, int e) {
+        const uint32_t i = row(32 * it + 8 * g + 4 * h + e);
+        qv[it][4 * g + e] = *reinterpret_cast<const float*>(qb + (i * rq + 4u * c));
+        dov[it][4 * g + e] = *reinterpret_cast<const float*>(dob + (i * rq + 4u * c));
+    });
+    char* dkb = reinterpret_cast<char*>(a.dkv + b2 * WT * 2 * a.C + head * HD);
+    char* dvb = dkb + 4 * a.C;
+    const float* st = a.stats + u * 192;
+#pragma unroll
+    for (int jt = 0; jt < 2; ++jt) {
+        f32x16 s[2], dp[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[it][r] = 0.f; dp[it][r] = 0.f; }
+        qk_product(s, qf, kf[jt]);                                        // S = Q K^T (unscaled; scale applied below)
+        qk_product(dp, dof, vkf[jt]);                                     // dP = dO V^T
+        const int kj = 32 * jt + c;
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (it == 1 && g == 3) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { s[it][4 * g + e] = 0.f; dp[it][4 * g + e] = 0.f; }
+                    continue;
+                }
+                const int i0 = 32 * it + 8 * g + 4 * h;
+                const f32x4 mv = *reinterpret_cast<const f32x4*>(st + i0);
+                const f32x4 iv = *reinterpret_cast<const f32x4*>(st + 64 + i0);
+                const f32x4 dv = *reinterpret_cast<const f32x4*>(st + 128 + i0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const bool valid = (i0 + e < WT) && (kj < WT);
+                    const float pr = valid ? __expf(s[it][4 * g + e] * a.scale - mv[e]) * iv[e] : 0.f;
+                    s[it][4 * g + e] = pr;
+                    dp[it][4 * g + e] = valid ? pr * (dp[it][4 * g + e] - dv[e]) * a.scale : 0.f;   // scale: dS/d(q k)
+                }
+            }
+        f32x16 ov, ok;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { ov[r] = 0.f; ok[r] = 0.f; }
+        pv_product(ov, s, dov);                                           // dV = P^T dO
+        pv_product(ok, dp, qv);                                           // dK = scale dS^T Q
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (jt == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;
+            const int j = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (j < WT) {
+                *reinterpret_cast<float*>(dvb + ((uint32_t)j * rk + 4u * c)) = ov[r];
+                *reinterpret_cast<float*>(dkb + ((uint32_t)j * rk + 4u * c)) = ok[r];
+            }
+        }
+    }
+}
+
 // dbias_full[head][i][j] = sum over that head's wave partials (fixed order: 4 lane groups take every 4th partial, then
 // the groups are combined in order); partial layout [it][jt][r][lane]
 __global__ __launch_bounds__(256) void win_attn_dbias_reduce_kernel(const float* __restrict__ part, float* __restrict__ full, int nH,
@@ -793,5 +967,31 @@ extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, c
     hipLaunchKernelGGL(win_attn_dtable_kernel, dim3(ntab, a.nH), dim3(64), 0, as_stream(stream), full, rel_index, dtable, a.nH,
                        ntab);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dtable)");
+    return 0;
+}
+
+extern "C" int64_t mumpy_deform_attention_bwd_workspace_bytes(int64_t B2w, int C) {
+    return (B2w <= 0 || C <= 0) ? 0 : B2w * (C / HD) * 192 * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_deform_attention_bwd(const float* q, const float* kv, const float* dout, float* dq_part, float* dkv,
+                                          void* workspace, int64_t workspace_bytes, int64_t B1w, int r, int C, float scale,
+                                          void* stream) {
+    MUMPY_REQUIRE(q && kv && dout && dq_part && dkv && workspace, MUMPY_ENULL, "deform_attention_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(q) && aligned16(kv) && aligned16(dout) && aligned16(dq_part) && aligned16(dkv) && aligned16(workspace),
+                  MUMPY_EALIGN, "deform_attention_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B1w > 0 && r >= 1 && C > 0 && C % HD == 0, MUMPY_EINVAL, "deform_attention_bwd: bad shape");
+    const int64_t B2w = B1w * r;
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_deform_attention_bwd_workspace_bytes(B2w, C), MUMPY_EINVAL,
+                  "deform_attention_bwd: workspace too small");
+    CrossBwdArgs a;
+    a.q = q; a.kv = kv; a.dout = dout; a.dq_part = dq_part; a.dkv = dkv; a.stats = static_cast<float*>(workspace);
+    a.C = C; a.nH = C / HD; a.r = r; a.B1w = (int)B1w; a.scale = scale; a.units = B2w * a.nH;
+    const int64_t grid = (a.units + 3) / 4;
+    MUMPY_REQUIRE(grid < (1ll << 31) && B1w < (1ll << 31), MUMPY_ERANGE, "deform_attention_bwd: too many windows");
+    hipLaunchKernelGGL(deform_attn_bwd_q_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    MUMPY_CHECK_LAUNCH("deform_attention_bwd(q)");
+    hipLaunchKernelGGL(deform_attn_bwd_kv_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    MUMPY_CHECK_LAUNCH("deform_attention_bwd(kv)");
     return 0;
 }

@@ -419,3 +419,57 @@ class DeformSampleFn(torch.autograd.Function):
     def backward(ctx, ds):
         x2w, pos = ctx.saved_tensors
         return ops.deform_sample_bwd(x2w, pos, ds.contiguous())
+
+
+class DeformAttentionFn(torch.autograd.Function):
+    """softmax(q k^T * scale) v per kv window with the reference's pairing (q window = kv window mod B1, deform:330) and the sum
+    over adjacent r-tuples (deform:394-395), window form: q (B1,49,C), kv (B1*r,49,2C) -> (B1,49,C)."""
+
+    @staticmethod
+    def forward(ctx, q, kv, scale):
+        b1, _, c = q.shape
+        r = kv.shape[0] // b1
+        ctx.save_for_backward(q, kv)
+        ctx.cfg = (r, scale)
+        return ops.deform_attention(q, kv, ops.pad_mask().to(q.device), b1, 7, 7, c, r, scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv = ctx.saved_tensors
+        dq, dkv = ops.deform_attention_bwd(q, kv, dout.contiguous(), *ctx.cfg)
+        return dq, dkv, None
+
+
+_REF_POINTS = {}
+
+
+def _ref_points(device):
+    key = str(device)
+    if key not in _REF_POINTS:
+        r = (torch.linspace(0.5, 6.5, 7) / 7.0) * 2.0 - 1.0                # deform:313-319
+        _REF_POINTS[key] = torch.stack(torch.meshgrid(r, r, indexing="ij"), -1).reshape(49, 2).to(device)
+    return _REF_POINTS[key]
+
+
+def swin_dattention_train(att, x1w, x2w):
+    """SwinDAttention.forward (deform:324-405) with a backward, window form: x1w (B1,49,C) q windows, x2w (B2,49,C) kv windows
+    (already through `pre`), B2 = r*B1 -> y (B1,49,C) including the un-permuted (C,49) -> (49,C) reshape of deform:403.
+    The offset network runs unfused (depthwise conv, LayerNorm, GELU, 1x1 conv as kernels; tanh / scaling / reference points
+    on the (B1,3,49,2) positions are a few KB of torch arithmetic)."""
+    b1, _, c = x1w.shape
+    g, cg = att.n_groups, att.n_group_channels
+    q = LinearFn.apply(x1w, att.proj_q.weight.reshape(c, c), att.proj_q.bias)
+    off = att.conv_offset
+    qg = q.reshape(b1, 49, g, cg).permute(0, 2, 1, 3).reshape(b1 * g, 49, cg).contiguous()
+    u = DWConv5Fn.apply(qg, off[0].weight, off[0].bias)
+    a = GeluFn.apply(LayerNormFn.apply(u, off[1].norm.weight, off[1].norm.bias, off[1].norm.eps))
+    wpw = torch.nn.functional.pad(off[3].weight.reshape(2, cg), (0, 0, 0, 30))            # N = 2 padded to the GEMM's multiple of 32
+    o2 = LinearFn.apply(a.reshape(-1, cg), wpw, None)[:, :2].reshape(b1, g, 49, 2)
+    pos = torch.tanh(o2) * (2.0 / 7.0) + _ref_points(x1w.device)                           # deform:339-349, (y, x)
+    samp = DeformSampleFn.apply(x2w.contiguous(), pos.contiguous())
+    wkv = torch.cat([att.proj_k.weight.reshape(c, c), att.proj_v.weight.reshape(c, c)], 0)
+    bkv = torch.cat([att.proj_k.bias, att.proj_v.bias])
+    kv = LinearFn.apply(samp, wkv, bkv)
+    o = DeformAttentionFn.apply(q, kv, att.scale)
+    yt = LinearFn.apply(o, att.proj_out.weight.reshape(c, c), att.proj_out.bias)
+    return yt.transpose(1, 2).reshape(b1, 49, c)

@@ -57,6 +57,8 @@ SIGNATURES = {
     "mumpy_dwconv5_window_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_f],
     "mumpy_dwconv5_window_bwd_workspace_bytes": [c_l, c_i],
     "mumpy_dwconv5_window_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_f],
+    "mumpy_deform_attention_bwd_workspace_bytes": [c_l, c_i],
+    "mumpy_deform_attention_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_i, c_fl, c_f],
     "mumpy_deform_sample_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }

@@ -554,3 +554,20 @@ def deform_sample_bwd(x2w, pos, dsampled):
     _call("mumpy_deform_sample_bwd", _p(x2w), _p(pos), _p(dsampled), _p(dx2), _p(part), b2, c, nq, _stream(), work=12.0 * x2w.numel())
     # kv windows qw + m*nq share q window qw: a (r, nq, ...) view summed over r (a few KB: left to torch)
     return dx2, part.view(b2 // nq, nq, 3, 49, 2).sum(0)
+
+
+def deform_attention_bwd(q, kv, dout, r, scale):
+    """window form: q (B1,49,C), kv (B1*r,49,2C), dout (B1,49,C) -> (dq (B1,49,C), dkv (B1*r,49,2C))."""
+    q, kv, dout = _chk(q, "q"), _chk(kv, "kv"), _chk(dout, "dout")
+    b1, _, c = q.shape
+    b2 = b1 * r
+    part = torch.empty(b2, 49, c, device=q.device, dtype=torch.float32)
+    dkv = torch.empty_like(kv)
+    wsb = int(_lib().mumpy_deform_attention_bwd_workspace_bytes(b2, c))
+    ws = _ws(wsb, q.device)
+    _call("mumpy_deform_attention_bwd", _p(q), _p(kv), _p(dout), _p(part), _p(dkv), _p(ws), wsb, b1, r, c, scale, _stream(),
+          work=5 * 153664.0 * b2 * (c // 32))
+    dq = part[:b1]
+    for m in range(1, r):                                                 # kv windows qw + m*B1 pair with q window qw: fixed order
+        dq = add(dq.contiguous(), part[m * b1:(m + 1) * b1].contiguous())
+    return dq.contiguous(), dkv

@@ -410,3 +410,52 @@ def test_hip_deform_sample_bwd(nq, r, c):
     assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
     assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5
     assert rel_err(pg.grad.cpu(), pr.grad) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b1,r,c", [(4, 1, 96), (2, 3, 192), (1, 5, 96), (3, 3, 384)])
+def test_hip_deform_attention_bwd(b1, r, c):
+    """attention core of SwinDAttention (deform:360-395) in window form: pairing b2 % B1, r-tuple sum, scale on the product."""
+    from mumpy_hip.autograd import DeformAttentionFn
+    b2, nh = b1 * r, c // 32
+    q, kv, do = seeded_randn(120, b1, 49, c), seeded_randn(121, b2, 49, 2 * c), seeded_randn(122, b1, 49, c)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    sel = torch.arange(b2) % b1
+    qh = qr[sel].reshape(b2, 49, nh, 32).transpose(1, 2)
+    k = kvr[..., :c].reshape(b2, 49, nh, 32).transpose(1, 2)
+    v = kvr[..., c:].reshape(b2, 49, nh, 32).transpose(1, 2)
+    attn = ((qh @ k.transpose(-2, -1)) * 32 ** -0.5).softmax(-1)
+    ref = (attn @ v).transpose(1, 2).reshape(b2, 49, c).reshape(b1, r, 49, c).sum(1)
+    ref.backward(do)
+    qg, kvg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    out = DeformAttentionFn.apply(qg, kvg, 32 ** -0.5)
+    out.backward(do.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(qg.grad.cpu(), qr.grad) < 2e-5 and rel_err(kvg.grad.cpu(), kvr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b1,r,c", [(4, 1, 96), (2, 3, 192), (2, 5, 96)])
+def test_hip_swin_dattention_backward_vs_oracle(b1, r, c):
+    """Whole SwinDAttention module (row 10), window form: output, both input gradients and every parameter gradient against
+    autograd on the oracle's swin_dattention (index quirks included)."""
+    from models.modules.deformableAttention import SwinDAttention
+    from mumpy_hip.autograd import swin_dattention_train
+    att = fill_module_(SwinDAttention(c, c // 32, 0.0, 3)).eval()
+    sd = {"a." + k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    x1, x2, g = seeded_randn(130, b1, 49, c), seeded_randn(131, b1 * r, 49, c), seeded_randn(132, b1, 49, c)
+    x1o, x2o = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    yo = O.swin_dattention(x1o, x2o, sd, "a")
+    (yo * g).sum().backward()
+    att = att.cuda()
+    x1g, x2g = x1.cuda().requires_grad_(True), x2.cuda().requires_grad_(True)
+    y = swin_dattention_train(att, x1g, x2g)
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 2e-5
+    assert rel_err(x1g.grad.cpu(), x1o.grad) < 2e-4 and rel_err(x2g.grad.cpu(), x2o.grad) < 2e-4
+    for name, prm in att.named_parameters():
+        assert prm.grad is not None, name
+        if name == "proj_k.bias":       # adds the same q.b_k to every key's score: softmax-invariant, the true gradient is 0
+            assert float(prm.grad.abs().max()) < 1e-5 and float(sd["a." + name].grad.abs().max()) < 1e-5
+            continue
+        assert rel_err(prm.grad.cpu(), sd["a." + name].grad) < 2e-4, name
