@@ -473,3 +473,90 @@ def swin_dattention_train(att, x1w, x2w):
     o = DeformAttentionFn.apply(q, kv, att.scale)
     yt = LinearFn.apply(o, att.proj_out.weight.reshape(c, c), att.proj_out.bias)
     return yt.transpose(1, 2).reshape(b1, 49, c)
+
+
+# ---------------------------------------------------------------------------------------------- the three-view encoder
+def _tubelet_tokens(x, proj, norm):
+    """One view of CrossThreeViewTokenize (mTVE:605-618): Conv3d(3 -> C, k = s = (t,4,4)) as a per-tubelet Linear + LayerNorm.
+    x (B,T,3,H,W) -> (B, (T//t)*(H/4)*(W/4), C), frames stacked on the token axis."""
+    w = proj.weight                                                       # (C, 3, t, 4, 4)
+    cout, ch, t, p, _ = w.shape
+    b, T, _, hh, ww = x.shape
+    tt = (T - t) // t + 1
+    cols = x[:, :tt * t].permute(0, 2, 1, 3, 4).reshape(b, ch, tt, t, hh // p, p, ww // p, p).permute(0, 2, 4, 6, 1, 3, 5, 7)
+    cols = cols.reshape(b * tt * (hh // p) * (ww // p), ch * t * p * p)
+    k = cols.shape[1]
+    pad = (-k) % 32
+    y = LinearFn.apply(torch.nn.functional.pad(cols, (0, pad)).contiguous(), torch.nn.functional.pad(w.reshape(cout, k), (0, pad)),
+                       proj.bias)
+    return LayerNormFn.apply(y, norm.weight, norm.bias, norm.eps).reshape(b, -1, cout)
+
+
+def _windows(x, hs, w):
+    """(B, hs*w, C) raster -> (B*nW, 49, C) window-major (window_partition, swin:54-66; a pure permutation)."""
+    b, _, c = x.shape
+    return x.view(b, hs // 7, 7, w // 7, 7, c).permute(0, 1, 3, 2, 4, 5).reshape(-1, 49, c)
+
+
+def cross_swin_block_train(blk, x1, x2):
+    """CrossSwinBlock.forward (mTVE:228-291) with a backward -> (x1_new, out); `out` is the W-MSA output before the residual,
+    which the next view's cross attention consumes (mTVE:275, 347-349).  x2 is ignored for the last view."""
+    _, w = blk.input_resolution
+    b, l1, c1 = x1.shape
+    hs1 = l1 // w
+    att = blk.attn
+    y = LayerNormFn.apply(x1, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    a = WindowAttentionFn.apply(LinearFn.apply(y, att.qkv.weight, att.qkv.bias), att.relative_position_bias_table,
+                                att.relative_position_index, (b, hs1, w, c1, 0, att.scale), None, None)
+    out = LinearFn.apply(a, att.proj.weight, att.proj.bias)
+    x1 = AddFn.apply(x1, drop_path_train(blk.drop_path, out))
+    if not blk.last_view:
+        hs2 = x2.shape[1] // w
+        x1w = _windows(x1, hs1, w).contiguous()
+        x2w = LinearFn.apply(_windows(x2, hs2, w).contiguous(), blk.pre.weight, blk.pre.bias)
+        yw = AddFn.apply(x1w, swin_dattention_train(blk.cva.crossattn, x1w, x2w))          # CVAModule: x1 + D (mTVE:138)
+        x1 = AddFn.apply(x1, yw.reshape(b, l1, c1))                       # window-major y added to raster x1 (mTVE:285-286)
+    z = LayerNormFn.apply(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    hmid = GeluFn.apply(LinearFn.apply(z, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
+    return AddFn.apply(x1, drop_path_train(blk.drop_path, LinearFn.apply(hmid, blk.mlp.fc2.weight, blk.mlp.fc2.bias))), out
+
+
+def encoder_train(enc, x):
+    """Encoder.forward (encoder.py:11-18; ThreeViewSwinTransformer.forward mTVE:732-746) with a backward:
+    x (B,T,3,224,224) -> (final_x (B,2304,7,7), view_x[4][3] of (B,1,L,C), dct_x (B,9,224,224)).  The DCT features carry no
+    parameters and are computed without a tape."""
+    m = enc.base
+    b = x.shape[0]
+    with torch.no_grad():
+        dct_x = m.faf.forward_frame(x, 1)
+    tok = m.tokenize
+    xs = [_tubelet_tokens(x, getattr(tok, f"project{v + 1}"), getattr(tok, f"norm{v + 1}")) for v in range(3)]
+    tdims = m.input_token_temporal_dims
+    view_x = []
+    for layer in m.layers.layers:
+        for i, blk in enumerate(layer.blocks):
+            if i == 0:                                                    # cross block: view 3 -> 2 -> 1 (mTVE:345-350)
+                xs[2], out2 = cross_swin_block_train(blk.block3, xs[2], None)
+                xs[1], out1 = cross_swin_block_train(blk.block2, xs[1], out2)
+                xs[0], _ = cross_swin_block_train(blk.block1, xs[0], out1)
+            else:
+                for v in range(3):
+                    sub = getattr(blk, f"block{v + 1}")
+                    if not isinstance(sub, torch.nn.Identity):
+                        xs[v] = swin_block_train(sub, xs[v])
+        view_x.append([t.unsqueeze(1) for t in xs])                       # captured before the downsample (mTVE:535)
+        if layer.downsample is not None:
+            xs = [patch_merging_train(getattr(layer.downsample, f"downsample{v + 1}"), xs[v]) for v in range(3)]
+    tmax = max(tdims)
+    parts = []
+    for v, t in enumerate(xs):                                            # merge_views_along_channel_axis (mTVE:710-718)
+        _, l, c = t.shape
+        parts.append(t.reshape(b, tdims[v], l // tdims[v], c).repeat(1, tmax // tdims[v], 1, 1))
+    g = torch.cat(parts, -1)                                              # (B, T, 49, 2560)
+    g = LinearFn.apply(g.contiguous(), m.globalembedding.weight, m.globalembedding.bias)
+    g = g.permute(0, 2, 1, 3).reshape(b * 49, tmax, g.shape[-1]).contiguous()               # site-major sequences of T tokens
+    for gb in m.globalblocks.blocks:
+        g = global_block_train(gb, g)
+    g = g.reshape(b, 49, tmax, -1)
+    final = torch.cat([g[:, :, 0], g[:, :, 1], g[:, :, 2]], -1)           # temporal slices 0,1,2 only (mTVE:745)
+    return final.reshape(b, 7, 7, -1).permute(0, 3, 1, 2), view_x, dct_x

@@ -459,3 +459,39 @@ def test_hip_swin_dattention_backward_vs_oracle(b1, r, c):
             assert float(prm.grad.abs().max()) < 1e-5 and float(sd["a." + name].grad.abs().max()) < 1e-5
             continue
         assert rel_err(prm.grad.cpu(), sd["a." + name].grad) < 2e-4, name
+
+
+@pytest.mark.gpu
+def test_hip_full_model_backward_vs_oracle():
+    """The whole three-view model (Encoder + Decoder, T=3, B=1) trained through mumpy_hip.autograd: mask logits and EVERY
+    parameter gradient (1085 encoder + 98 decoder parameters) against autograd on the reference-pinned oracle."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    from mumpy_hip.autograd import decoder_train, encoder_train
+    enc, dec = fill_module_(Encoder()).eval(), fill_module_(Decoder()).eval()
+
+    def leaf_sd(mod):
+        return {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "attn_mask" not in k else v)
+                for k, v in mod.state_dict().items()}
+    sde, sdd = leaf_sd(enc), leaf_sd(dec)
+    x = seeded_randn(990, 1, 3, 3, 224, 224)
+    g = seeded_randn(991, 1, 1, 224, 224)
+    lo = O.full_forward(sde, sdd, x)[0]
+    (lo * g).sum().backward()
+    enc, dec = enc.cuda(), dec.cuda()
+    fx, vx, dx = encoder_train(enc, x.cuda())
+    lg, _ = decoder_train(dec, fx, vx, dx)
+    (lg * g.cuda()).sum().backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-3
+    bad = []
+    for mod, sd in ((enc, sde), (dec, sdd)):
+        for name, prm in mod.named_parameters():
+            assert prm.grad is not None, name
+            ref = sd[name].grad
+            if name.endswith("crossattn.proj_k.bias"):          # softmax-invariant: true gradient 0
+                assert float(prm.grad.abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()) * 1e4), name
+                continue
+            e = rel_err(prm.grad.cpu(), ref)
+            if e > 1e-2:
+                bad.append((name, e))
+    assert not bad, bad[:10]
