@@ -82,8 +82,15 @@ class FlatAdamW:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return 1.0
         per = max(1, bucket_bytes // 4)
+        host = self.grad.is_cuda and dist.get_backend() == "gloo"        # CPU rehearsal backend: stage each bucket on the host
         for o in range(0, self.grad.numel(), per):
-            dist.all_reduce(self.grad[o:o + per], op=dist.ReduceOp.SUM)
+            bucket = self.grad[o:o + per]
+            if host:
+                h = bucket.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.SUM)
+                bucket.copy_(h)
+            else:
+                dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
         return 1.0 / dist.get_world_size()
 
     def step(self, grad_scale: float = 1.0):

@@ -190,3 +190,54 @@ def test_flat_adamw_trains_like_torch_adamw():
         assert lr == ref.param_groups[0]["lr"]
     for a, b in zip(net.parameters(), twin.parameters()):
         assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-5
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from conftest import PKG  # noqa: F401
+    from weight_fill import fill_module_
+    from models.modules.swinTransformer import SwinTransformerBlock
+    from mumpy_hip import distributed as D
+    from mumpy_hip.autograd import swin_block_train
+    from mumpy_hip.train import FlatAdamW
+    D.init_process_group("gloo")
+    dev = torch.device("cuda:0")
+    blk = fill_module_(SwinTransformerBlock(dim=96, input_resolution=(14, 14), num_heads=3, window_size=7, shift_size=3)).to(dev)
+    opt = FlatAdamW(blk.parameters(), lr=1e-3, weight_decay=1e-4)
+    x = seeded_randn(300 + rank, 2, 196, 96).to(dev)               # this rank's micro-batch
+    g = seeded_randn(310 + rank, 2, 196, 96).to(dev)
+    swin_block_train(blk, x).backward(g)
+    scale = opt.all_reduce_grads(bucket_bytes=1 << 16)               # several buckets
+    opt.step(grad_scale=scale)
+    q.put((rank, opt.param.cpu().numpy()))            # numpy: a torch tensor in the queue is shared by fd and can outlive its owner
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_two_rank_training_step_matches_accumulated_single_process():
+    """Two ranks (sharing the one GPU of the test box, gloo standing in for RCCL), one Swin block, one step: after the bucketed
+    gradient all-reduce and the fused AdamW both ranks hold the same parameters, equal to one process that accumulated the
+    two micro-batches' gradients and stepped with grad_scale = 1/2."""
+    from weight_fill import fill_module_
+    from models.modules.swinTransformer import SwinTransformerBlock
+    from mumpy_hip.autograd import swin_block_train
+    from mumpy_hip.train import FlatAdamW
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: torch.from_numpy(a) for r, a in (q.get(timeout=300) for _ in procs)}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert torch.equal(res[0], res[1])
+    dev = torch.device("cuda:0")
+    blk = fill_module_(SwinTransformerBlock(dim=96, input_resolution=(14, 14), num_heads=3, window_size=7, shift_size=3)).to(dev)
+    opt = FlatAdamW(blk.parameters(), lr=1e-3, weight_decay=1e-4)
+    for rank in range(2):                                            # autograd accumulates into the flat gradient views
+        swin_block_train(blk, seeded_randn(300 + rank, 2, 196, 96).to(dev)).backward(seeded_randn(310 + rank, 2, 196, 96).to(dev))
+    opt.step(grad_scale=0.5)
+    assert rel_err(res[0], opt.param.cpu()) < 1e-6
