@@ -17,6 +17,9 @@ namespace {
 // partial row per wave; ln_bwd_reduce_kernel sums the partials in order.
 constexpr int LN_MAXC4 = 8;             // float4 columns per lane: C <= 64 * 4 * 8 = 2048 (PatchMerging's LayerNorm(4C) at C = 512)
 
+// NC4 = float4 columns per lane (C <= 256 * NC4), RU = rows in flight per wave: narrow rows are latency-bound (three
+// dependent wave reductions per row), so several independent rows are interleaved
+template <int NC4, int RU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ dy, float* __restrict__ dx,
                                                      float* __restrict__ partial, int64_t rows, int C, float eps,
@@ -24,55 +27,89 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int n4 = C >> 2;                                  // float4 columns
-    f32x4 dg[LN_MAXC4], db[LN_MAXC4];
+    const float invc = 1.0f / (float)C;
+    f32x4 dg[NC4], db[NC4], gm[NC4];
 #pragma unroll
-    for (int i = 0; i < LN_MAXC4; ++i) { dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0}; }
+    for (int i = 0; i < NC4; ++i) {
+        dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0};
+        const int c4 = lane + 64 * i;
+        gm[i] = c4 < n4 ? reinterpret_cast<const f32x4*>(gamma)[c4] : f32x4{0, 0, 0, 0};
+    }
     const int64_t r0 = gw * rows_per_wave;
-    for (int64_t r = r0; r < r0 + rows_per_wave && r < rows; ++r) {
-        const f32x4* xr = reinterpret_cast<const f32x4*>(x + r * C);
-        const f32x4* dyr = reinterpret_cast<const f32x4*>(dy + r * C);
-        f32x4 xv[LN_MAXC4], gv[LN_MAXC4];
-        float s = 0.f;
+    const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
+    for (int64_t rb = r0; rb < r1; rb += RU) {
+        f32x4 xv[RU][NC4], dv[RU][NC4];
+        float s[RU], q[RU], sg[RU], sgx[RU];
 #pragma unroll
-        for (int i = 0; i < LN_MAXC4; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < n4) { xv[i] = xr[c4]; s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w); }
-        }
-        const float mean = wave_sum(s, 64) / (float)C;
-        float v = 0.f;
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = (rb + u < r1) ? rb + u : r1 - 1;                 // tail rows recompute the last row (not stored)
+            s[u] = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_MAXC4; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < n4) { xv[i] -= mean; v += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w); }
-        }
-        const float rstd = rsqrtf(wave_sum(v, 64) / (float)C + eps);
-        float sg = 0.f, sgx = 0.f;
-#pragma unroll
-        for (int i = 0; i < LN_MAXC4; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < n4) {
-                const f32x4 d = dyr[c4];
-                const f32x4 gm = reinterpret_cast<const f32x4*>(gamma)[c4];
-                xv[i] *= rstd;                                  // xhat
-                gv[i] = d * gm;
-                db[i] += d;
-                dg[i] += d * xv[i];
-                sg += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
-                sgx += (gv[i].x * xv[i].x + gv[i].y * xv[i].y) + (gv[i].z * xv[i].z + gv[i].w * xv[i].w);
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    xv[u][i] = reinterpret_cast<const f32x4*>(x + r * C)[c4];
+                    dv[u][i] = reinterpret_cast<const f32x4*>(dy + r * C)[c4];
+                    s[u] += (xv[u][i].x + xv[u][i].y) + (xv[u][i].z + xv[u][i].w);
+                } else { xv[u][i] = f32x4{0, 0, 0, 0}; dv[u][i] = f32x4{0, 0, 0, 0}; }
             }
         }
-        const float mg = wave_sum(sg, 64) / (float)C, mgx = wave_sum(sgx, 64) / (float)C;
-        f32x4* dxr = reinterpret_cast<f32x4*>(dx + r * C);
 #pragma unroll
-        for (int i = 0; i < LN_MAXC4; ++i) {
-            const int c4 = lane + 64 * i;
-            if (c4 < n4) dxr[c4] = (gv[i] - mg - xv[i] * mgx) * rstd;
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) s[u] += __shfl_xor(s[u], o);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float mean = s[u] * invc;
+            q[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    xv[u][i] -= mean;
+                    q[u] += (xv[u][i].x * xv[u][i].x + xv[u][i].y * xv[u][i].y) + (xv[u][i].z * xv[u][i].z + xv[u][i].w * xv[u][i].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) q[u] += __shfl_xor(q[u], o);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float rstd = rsqrtf(q[u] * invc + eps);
+            const bool live = rb + u < r1;
+            q[u] = rstd;
+            sg[u] = 0.f; sgx[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                xv[u][i] *= rstd;                                              // xhat
+                if (live) { db[i] += dv[u][i]; dg[i] += dv[u][i] * xv[u][i]; }
+                dv[u][i] *= gm[i];                                             // g = dy * gamma
+                sg[u] += (dv[u][i].x + dv[u][i].y) + (dv[u][i].z + dv[u][i].w);
+                sgx[u] += (dv[u][i].x * xv[u][i].x + dv[u][i].y * xv[u][i].y) + (dv[u][i].z * xv[u][i].z + dv[u][i].w * xv[u][i].w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) { sg[u] += __shfl_xor(sg[u], o); sgx[u] += __shfl_xor(sgx[u], o); }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (rb + u >= r1) continue;
+            const float mg = sg[u] * invc, mgx = sgx[u] * invc, rstd = q[u];
+            f32x4* dxr = reinterpret_cast<f32x4*>(dx + (rb + u) * C);
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) dxr[c4] = (dv[u][i] - mg - xv[u][i] * mgx) * rstd;
+            }
         }
     }
     f32x4* pg = reinterpret_cast<f32x4*>(partial + gw * 2 * C);
     f32x4* pb = reinterpret_cast<f32x4*>(partial + gw * 2 * C + C);
 #pragma unroll
-    for (int i = 0; i < LN_MAXC4; ++i) {
+    for (int i = 0; i < NC4; ++i) {
         const int c4 = lane + 64 * i;
         if (c4 < n4) { pg[c4] = dg[i]; pb[c4] = db[i]; }
     }
@@ -334,7 +371,7 @@ static int64_t ln_bwd_waves(int64_t rows) {            // waves (= partial rows)
 
 extern "C" int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
-    return ln_bwd_waves(rows) * 2 * C * (int64_t)sizeof(float);
+    return (ln_bwd_waves(rows) + 1) * 2 * C * (int64_t)sizeof(float);      // partial rows + one reduced [dgamma | dbeta] row
 }
 
 extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
@@ -348,16 +385,23 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
     const int64_t waves = ln_bwd_waves(rows);
     const int rpw = (int)((rows + waves - 1) / waves);
     float* partial = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx, partial,
-                       rows, C, eps, rpw);
+#define MUMPY_LN_BWD(NC4_, RU_)                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx, \
+                       partial, rows, C, eps, rpw)
+    if (C <= 256) MUMPY_LN_BWD(1, 4);
+    else if (C <= 512) MUMPY_LN_BWD(2, 2);
+    else if (C <= 1024) MUMPY_LN_BWD(4, 1);
+    else MUMPY_LN_BWD(8, 1);
+#undef MUMPY_LN_BWD
     MUMPY_CHECK_LAUNCH("layernorm_bwd");
-    // partial rows are [dgamma(C) | dbeta(C)] per wave; dgamma and dbeta are separate caller buffers: two strided reduces
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, dgamma,
-                       waves, (int64_t)C, (int64_t)2 * C);
-    MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce dgamma)");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial + C, dbeta,
-                       waves, (int64_t)C, (int64_t)2 * C);
-    MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce dbeta)");
+    // partial rows are [dgamma(C) | dbeta(C)] per wave: one reduce over width 2C into a scratch row, then two small copies
+    float* both = partial + waves * 2 * C;
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, both,
+                       waves, (int64_t)2 * C, (int64_t)2 * C);
+    MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce)");
+    hipError_t e1 = hipMemcpyAsync(dgamma, both, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
+    hipError_t e2 = hipMemcpyAsync(dbeta, both + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
+    MUMPY_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, (int)(e1 != hipSuccess ? e1 : e2), "layernorm_bwd: copy of the reduced gradients failed");
     return 0;
 }
 

@@ -231,11 +231,6 @@ class GroupNormActFn(torch.autograd.Function):
         return dz, dg, db, None, None, None
 
 
-class GroupNormReluFn:
-    @staticmethod
-    def apply(z, gamma, beta, groups, eps):
-        return GroupNormActFn.apply(z, gamma, beta, groups, eps, ops.ACT_RELU)
-
 
 class UpsampleFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=scale, mode="bilinear", align_corners=...) on NHWC, scale in {2, 4}."""
@@ -249,11 +244,6 @@ class UpsampleFn(torch.autograd.Function):
     def backward(ctx, dy):
         return ops.upsample_bwd(dy, *ctx.cfg), None, None
 
-
-class Upsample2xFn:
-    @staticmethod
-    def apply(x, align_corners):
-        return UpsampleFn.apply(x, 2, align_corners)
 
 
 class FinalConvFn(torch.autograd.Function):
@@ -288,8 +278,8 @@ def baseline_decoder_train(dec, x):
     for i in range(5):
         conv, gn = getattr(dec, f"decoder_{i + 1}")[0], getattr(dec, f"decoder_{i + 1}")[1]
         z = Conv2dFn.apply(x, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias)
-        a = GroupNormReluFn.apply(z, gn.weight, gn.bias, gn.num_groups, gn.eps)
-        x = Upsample2xFn.apply(a, True)
+        a = GroupNormActFn.apply(z, gn.weight, gn.bias, gn.num_groups, gn.eps, ops.ACT_RELU)
+        x = UpsampleFn.apply(a, 2, True)
     return FinalConvFn.apply(x, dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)
 
 

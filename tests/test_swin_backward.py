@@ -165,14 +165,15 @@ def test_hip_baseline_encoder_backward_vs_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("b,h,w,c,g", [(2, 14, 14, 256, 32), (1, 7, 9, 64, 8)])
 def test_hip_groupnorm_relu_bwd(b, h, w, c, g):
-    from mumpy_hip.autograd import GroupNormReluFn
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import GroupNormActFn
     z = seeded_randn(30, b, c, h, w) * 2 + 0.3
     gm, bt, dy = 1 + 0.1 * seeded_randn(31, c), 0.1 * seeded_randn(32, c), seeded_randn(33, b, c, h, w)
     zr, gr, br = [t.clone().requires_grad_(True) for t in (z, gm, bt)]
     F.relu(F.group_norm(zr, g, gr, br, 1e-5)).backward(dy)
     zg = z.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     gg, bg = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
-    GroupNormReluFn.apply(zg, gg, bg, g, 1e-5).backward(dy.cuda())
+    GroupNormActFn.apply(zg, gg, bg, g, 1e-5, ops.ACT_RELU).backward(dy.cuda())
     assert rel_err(zg.grad.cpu(), zr.grad) < 5e-5 and rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
 
 
