@@ -463,20 +463,23 @@ def test_hip_swin_dattention_backward_vs_oracle(b1, r, c):
 
 
 @pytest.mark.gpu
-def test_hip_full_model_backward_vs_oracle():
-    """The whole three-view model (Encoder + Decoder, T=3, B=1) trained through mumpy_hip.autograd: mask logits and EVERY
-    parameter gradient (1085 encoder + 98 decoder parameters) against autograd on the reference-pinned oracle."""
+@pytest.mark.parametrize("b,t", [(1, 3), (2, 5)])
+def test_hip_full_model_backward_vs_oracle(b, t):
+    """The whole three-view model (Encoder + Decoder) trained through mumpy_hip.autograd: mask logits and EVERY parameter
+    gradient (1085 encoder + 98 decoder parameters) against autograd on the reference-pinned oracle.  (1,3) is the canonical
+    graph; (2,5) is the north-star shape per clip (tubelets (5,4,1), r = 5 in the view-2 cross attention) with two clips in
+    the micro-batch, so the cross-sample coupling of SwinDAttention (deform:330,394) is differentiated too."""
     from models.decoder.decoder import Decoder
     from models.encoder.encoder import Encoder
     from mumpy_hip.autograd import decoder_train, encoder_train
-    enc, dec = fill_module_(Encoder()).eval(), fill_module_(Decoder()).eval()
+    enc, dec = fill_module_(Encoder(num_frames=t)).eval(), fill_module_(Decoder(input_token_temporal_dims=[1, 1, t])).eval()
 
     def leaf_sd(mod):
         return {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "attn_mask" not in k else v)
                 for k, v in mod.state_dict().items()}
     sde, sdd = leaf_sd(enc), leaf_sd(dec)
-    x = seeded_randn(990, 1, 3, 3, 224, 224)
-    g = seeded_randn(991, 1, 1, 224, 224)
+    x = seeded_randn(990, b, t, 3, 224, 224)
+    g = seeded_randn(991, b, 1, 224, 224)
     lo = O.full_forward(sde, sdd, x)[0]
     (lo * g).sum().backward()
     enc, dec = enc.cuda(), dec.cuda()
