@@ -7,7 +7,6 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "tests", "golden"),
                 os.path.join(ROOT, "multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd")]
 from weight_fill import fill_module_
 from models.modules.swinTransformer import SwinTransformerBlock
-from mumpy_hip import ops
 from mumpy_hip.autograd import swin_block_train
 from mumpy_hip.train import FlatAdamW
 stage = int(sys.argv[1]) if len(sys.argv) > 1 else 2
@@ -18,8 +17,6 @@ blk = fill_module_(SwinTransformerBlock(dim=c, input_resolution=(side, side), nu
 opt = FlatAdamW(blk.parameters(), lr=1e-4)
 x = torch.randn(8, 5 * side * side, c, device=dev, requires_grad=True)
 g = torch.randn_like(x)
-prof = {}
-ops.PROFILE = prof if hasattr(ops, "PROFILE") else None
 def step():
     y = swin_block_train(blk, x)
     y.backward(g)

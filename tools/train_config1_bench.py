@@ -18,15 +18,12 @@ dec = fill_module_(BaselineDecoder(in_channels=1024)).eval().to(dev)
 opts = build_optimizers(enc, dec, lr_cnn=1e-6, lr=1e-5, weight_decay=1e-4, weight_decay_cnn=1e-4)
 x = seeded_randn(1, B, 3, 3, 224, 224).to(dev)
 target = (torch.rand(B, 1, 224, 224, device=dev) < 0.1).float()
-prof = {}
-def step(record=None):
-    ops.PROFILE = record
+def step():
     logits = baseline_decoder_train(dec, baseline_encoder_train(enc, x))
     loss3, dlogits = ops.mask_loss(logits.detach(), target)
     logits.backward(dlogits)
     for o in opts.values():
         o.step(); o.zero_grad()
-    ops.PROFILE = None
     return loss3
 for _ in range(2):
     step()
