@@ -1,5 +1,6 @@
 /* mumpy_hip.h — C ABI of libmumpy_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
- * forward hot path of Mumpy (Multilateral Temporal-view Pyramid Transformer).
+ * hot path of Mumpy (Multilateral Temporal-view Pyramid Transformer): the forward (inference) entry points first, the
+ * training entry points (loss, optimizer, backward kernels) at the end.
  *
  * The reference is pure Python/PyTorch and has no FFI of its own; the "interface" each entry point
  * replaces is therefore the reference Python operator it computes, cited as file:line below
