@@ -11,7 +11,13 @@ Each function cites the reference file:line it follows (paths relative to /root/
 Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against the
 fixtures in tests/golden/ that tests/golden/gen_goldens.py produced by running the real
 reference in the build container (per-operator outputs, integer index maps, and whole-model
-outputs for B=1/T=3, B=2/T=3 (cross-sample coupling) and B=1/T=5).
+outputs for B=1/T=3, B=2/T=3 (cross-sample coupling), B=1/T=5, and config 1's encoder + decoder).
+
+Backward: the functions are differentiable torch code, so torch autograd on them is the gradient oracle of the training
+kernels.  That use is pinned as well: tests/test_swin_backward.py::test_oracle_autograd_matches_reference_block checks
+output, input gradient and all parameter gradients of `swin_block` against the reference's own SwinTransformerBlock run
+under autograd, and tests/test_train_tail.py checks `mask_loss` / `polynomial_lr_sequence` against the reference's
+utils/loss.py and utils/optimizer/scheduler.py (fixtures: tests/golden/train_tail.npz, tests/golden/gen_train_goldens.py).
 """
 from __future__ import annotations
 
