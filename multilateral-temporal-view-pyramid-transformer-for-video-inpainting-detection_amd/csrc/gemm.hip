@@ -543,12 +543,6 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split) {
     // with more than one wide tile queued per CU and a deep enough K, the 4-wave 64x64-per-wave DMA variant (two
     // co-resident blocks, lowest LDS-read ratio) measured 4-9 % faster than the 8-wave pipelined one
     if (tile == 0 && b128 > NUM_CU && K >= 512) tile = 3;
-    // the same variant also wins (4-10 us on the forward's shapes) whenever its grid fills whole rounds of its 512 resident
-    // slots (2 blocks per CU): fewer LDS bytes per MFMA than the 64x64 tile at no quantisation loss
-    if (K >= 512 && b128 >= (int64_t)(0.85 * 2 * NUM_CU)) {
-        const double rounds = (double)b128 / (2.0 * NUM_CU), frac = rounds - (double)(int64_t)rounds;
-        if (frac == 0.0 || frac >= 0.85) tile = 3;
-    }
     int ks = 1;
     if (tile == 2 && allow_split && b64 < 2 * NUM_CU && K >= 768) {
         ks = (int)((3 * NUM_CU + b64 - 1) / b64);
