@@ -213,6 +213,14 @@ int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp
                      double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
                      void* stream);
 
+/* the same update with its 8 step-dependent constants read from DEVICE memory, for hipGraph replay of a training step (the
+ * launch is frozen at capture; lr, bias corrections and gradient scale are not).  mumpy_adamw_hyper fills a HOST array of 8
+ * floats with exactly the constants mumpy_adamw_step would use; the caller copies it to `hyper_dev` before each replay. */
+int mumpy_adamw_hyper(float* out8_host, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                      double grad_scale);
+int mumpy_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                         const float* hyper_dev, void* stream);
+
 /* ---- backward kernels of the Swin block (rows 5-7 of 8a in training) ---------------------------------
  * LayerNorm backward (swin:266,305): x, dy, dx (rows,C); gamma, dgamma, dbeta (C); C % 4 == 0, C <= 2048.
  * workspace: mumpy_layernorm_bwd_workspace_bytes(rows, C) bytes of device scratch.  Deterministic. */

@@ -13,6 +13,7 @@
 //
 // AdamW: torch.optim.AdamW single-tensor semantics (utils/utils.py:258; decoupled weight decay, bias correction) over a
 // FLAT parameter buffer: one launch per parameter group instead of one per tensor.  28 B of HBM traffic per parameter.
+#include <string.h>
 #include "common.h"
 using namespace mumpy;
 
@@ -122,13 +123,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void mask_loss_grad_kernel(const floa
     }
 }
 
+struct AdamHyper {
+    float decay, omb1, beta2, omb2, eps, step_size, bc2_sqrt, grad_scale;   // all derived on the host in double
+};
 struct AdamArgs {
     float* p; const float* g; float* m; float* v;
     int64_t n;
-    float decay, omb1, beta2, omb2, eps, step_size, bc2_sqrt, grad_scale;   // all derived on the host in double
+    AdamHyper h;
+    const AdamHyper* hdev;      // if set, the hyper-parameters are read from this DEVICE buffer (hipGraph replay: the launch is
+                                // frozen at capture, the step-dependent constants are not)
 };
 
-__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamHyper& a) {
     g *= a.grad_scale;
     p *= a.decay;                                       // param.mul_(1 - lr * weight_decay)
     m = m + a.omb1 * (g - m);                           // exp_avg.lerp_(grad, 1 - beta1)
@@ -138,6 +144,7 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
+    const AdamHyper hy = a.hdev ? *a.hdev : a.h;
     const int64_t n4 = a.n >> 2;
     const int64_t stride = (int64_t)gridDim.x * 256;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
@@ -146,13 +153,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float pe = p[e], me = m[e], ve = v[e];
-            adam_one(pe, g[e], me, ve, a);
+            adam_one(pe, g[e], me, ve, hy);
             p[e] = pe; m[e] = me; v[e] = ve;
         }
         reinterpret_cast<f32x4*>(a.p)[i] = p; reinterpret_cast<f32x4*>(a.m)[i] = m; reinterpret_cast<f32x4*>(a.v)[i] = v;
     }
     const int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x;       // tail (< 4 elements)
-    if (i < a.n) adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    if (i < a.n) adam_one(a.p[i], a.g[i], a.m[i], a.v[i], hy);
 }
 
 int loss_splits(int B, int64_t P) {            // enough blocks to fill the chip, chunks of >= 2048 elements
@@ -188,27 +195,57 @@ extern "C" int mumpy_mask_loss_fwd_bwd(const float* logits, const float* target,
     return 0;
 }
 
-extern "C" int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
-                                double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
-                                void* stream) {
-    if (n == 0) return 0;
+static void adam_hyper(AdamHyper& h, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                       double grad_scale) {
+    // the scalars torch hands to its fp32 tensor ops are Python doubles rounded once to float: do the same
+    h.decay = (float)(1.0 - lr * weight_decay); h.omb1 = (float)(1.0 - beta1); h.beta2 = (float)beta2;
+    h.omb2 = (float)(1.0 - beta2); h.eps = (float)eps; h.grad_scale = (float)grad_scale;
+    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+    h.step_size = (float)(lr / bc1);
+    h.bc2_sqrt = (float)sqrt(bc2);
+}
+
+static int adamw_launch(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const AdamHyper* host,
+                        const float* hyper_dev, void* stream) {
     MUMPY_REQUIRE(param && grad && exp_avg && exp_avg_sq, MUMPY_ENULL, "adamw: null pointer");
     MUMPY_REQUIRE(aligned16(param) && aligned16(grad) && aligned16(exp_avg) && aligned16(exp_avg_sq), MUMPY_EALIGN,
                   "adamw: buffers must be 16-byte aligned");
-    MUMPY_REQUIRE(n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., MUMPY_EINVAL,
-                  "adamw: bad arguments (n=%lld step=%d)", (long long)n, step);
     AdamArgs a;
     a.p = param; a.g = grad; a.m = exp_avg; a.v = exp_avg_sq; a.n = n;
-    // the scalars torch hands to its fp32 tensor ops are Python doubles rounded once to float: do the same
-    a.decay = (float)(1.0 - lr * weight_decay); a.omb1 = (float)(1.0 - beta1); a.beta2 = (float)beta2;
-    a.omb2 = (float)(1.0 - beta2); a.eps = (float)eps; a.grad_scale = (float)grad_scale;
-    const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-    a.step_size = (float)(lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
+    a.hdev = reinterpret_cast<const AdamHyper*>(hyper_dev);
+    if (host) a.h = *host; else a.h = AdamHyper{1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 1.f, 0.f};
     int64_t grid = ((n >> 2) + 255) / 256;
     if (grid > 4096) grid = 4096;
     if (grid < 1) grid = 1;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("adamw");
     return 0;
+}
+
+extern "C" int mumpy_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr,
+                                double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
+                                void* stream) {
+    if (n == 0) return 0;
+    MUMPY_REQUIRE(n > 0 && step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., MUMPY_EINVAL,
+                  "adamw: bad arguments (n=%lld step=%d)", (long long)n, step);
+    AdamHyper h;
+    adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, &h, nullptr, stream);
+}
+
+extern "C" int mumpy_adamw_hyper(float* out8, double lr, double beta1, double beta2, double eps, double weight_decay, int step,
+                                 double grad_scale) {
+    MUMPY_REQUIRE(out8, MUMPY_ENULL, "adamw_hyper: null pointer");
+    MUMPY_REQUIRE(step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1., MUMPY_EINVAL, "adamw_hyper: bad arguments");
+    AdamHyper h;
+    adam_hyper(h, lr, beta1, beta2, eps, weight_decay, step, grad_scale);
+    memcpy(out8, &h, sizeof(h));
+    return 0;
+}
+
+extern "C" int mumpy_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                    const float* hyper_dev, void* stream) {
+    if (n == 0) return 0;
+    MUMPY_REQUIRE(n > 0 && hyper_dev, MUMPY_EINVAL, "adamw_step_dev: bad arguments");
+    return adamw_launch(param, grad, exp_avg, exp_avg_sq, n, nullptr, hyper_dev, stream);
 }

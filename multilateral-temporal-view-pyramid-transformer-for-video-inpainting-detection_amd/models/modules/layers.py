@@ -65,7 +65,10 @@ class Derived:
         self._val = None
 
     def get(self, sources, fn):
-        key = (weights_epoch[0],) + tuple((s.data_ptr(), s._version, str(s.device)) for s in sources)
+        # the optimizer epoch only matters for sources an optimizer can rewrite (parameters); buffers such as attn_mask keep
+        # their cache across steps (and stay host-sync free inside a captured training step)
+        epoch = weights_epoch[0] if any(getattr(s, "requires_grad", False) for s in sources) else 0
+        key = (epoch,) + tuple((s.data_ptr(), s._version, str(s.device)) for s in sources)
         if key != self._key:
             with torch.no_grad():
                 self._val = fn()

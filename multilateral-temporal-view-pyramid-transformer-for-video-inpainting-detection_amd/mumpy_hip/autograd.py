@@ -421,7 +421,7 @@ class DeformAttentionFn(torch.autograd.Function):
         r = kv.shape[0] // b1
         ctx.save_for_backward(q, kv)
         ctx.cfg = (r, scale)
-        return ops.deform_attention(q, kv, ops.pad_mask().to(q.device), b1, 7, 7, c, r, scale)
+        return ops.deform_attention(q, kv, ops.pad_mask(q.device), b1, 7, 7, c, r, scale)
 
     @staticmethod
     def backward(ctx, dout):

@@ -60,6 +60,8 @@ SIGNATURES = {
     "mumpy_deform_attention_bwd_workspace_bytes": [c_l, c_i],
     "mumpy_deform_attention_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_i, c_fl, c_f],
     "mumpy_deform_sample_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_f],
+    "mumpy_adamw_hyper": [ctypes.POINTER(ctypes.c_float), c_d, c_d, c_d, c_d, c_d, c_i, c_d],
+    "mumpy_adamw_step_dev": [c_f, c_f, c_f, c_f, c_l, c_f, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }
 ABI_VERSION = 1

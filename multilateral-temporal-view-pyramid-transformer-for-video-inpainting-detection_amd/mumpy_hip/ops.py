@@ -233,10 +233,19 @@ def expand_relpos_bias(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor
     return out
 
 
-def pad_mask() -> torch.Tensor:
-    m = torch.zeros(1, 64, 64, dtype=torch.float32)
-    m[:, :, 49:] = NEG
-    return m
+_PAD_MASK = {}
+
+
+def pad_mask(device=None) -> torch.Tensor:
+    """(1,64,64) key-padding mask of the deformable attention (0 / -1e30 on key columns >= 49); cached per device."""
+    if device is None:
+        m = torch.zeros(1, 64, 64, dtype=torch.float32)
+        m[:, :, 49:] = NEG
+        return m
+    key = str(device)
+    if key not in _PAD_MASK:
+        _PAD_MASK[key] = pad_mask().to(device)
+    return _PAD_MASK[key]
 
 
 def compact_attn_mask(mask: torch.Tensor):
@@ -571,3 +580,26 @@ def deform_attention_bwd(q, kv, dout, r, scale):
     for m in range(1, r):                                                 # kv windows qw + m*B1 pair with q window qw: fixed order
         dq = add(dq.contiguous(), part[m * b1:(m + 1) * b1].contiguous())
     return dq.contiguous(), dkv
+
+
+def adamw_hyper(step, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, grad_scale=1.0):
+    """The 8 fp32 constants of one AdamW step as a pinned host tensor (for adamw_step_dev under hipGraph replay)."""
+    import ctypes
+    out = torch.empty(8, dtype=torch.float32).pin_memory()
+    rc = _lib().mumpy_adamw_hyper(ctypes.cast(out.data_ptr(), ctypes.POINTER(ctypes.c_float)), lr, betas[0], betas[1], eps,
+                                  weight_decay, int(step), grad_scale)
+    if rc != 0:
+        raise RuntimeError(f"mumpy_adamw_hyper failed (rc={rc}): {_lib().mumpy_last_error().decode()}")
+    return out
+
+
+def adamw_step_dev(param, grad, exp_avg, exp_avg_sq, hyper_dev):
+    """AdamW over flat buffers with the step constants in the device tensor `hyper_dev` (8 floats): capturable."""
+    n = param.numel()
+    for name, t in (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)):
+        _chk(t, name)
+        if t.numel() != n or not t.is_contiguous():
+            raise RuntimeError(f"adamw_step_dev: {name} must be a contiguous buffer of {n} elements (in-place update)")
+    _call("mumpy_adamw_step_dev", _p(param), _p(grad), _p(exp_avg), _p(exp_avg_sq), n, _p(_chk(hyper_dev, "hyper")), _stream(),
+          work=28.0 * n)
+    return param

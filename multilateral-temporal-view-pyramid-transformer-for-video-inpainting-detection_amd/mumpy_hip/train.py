@@ -99,6 +99,23 @@ class FlatAdamW:
                        self.weight_decay, grad_scale)
         bump_weights_epoch()              # weight-derived caches (models.modules.layers.Derived) must be rebuilt
 
+    # ---- hipGraph replay: the launch is frozen at capture, so the step-dependent constants live in device memory ----
+    def enable_device_hyper(self):
+        self.hyper_dev = torch.zeros(8, device=self.param.device, dtype=torch.float32)
+
+    def stage_hyper(self, grad_scale: float = 1.0, advance: bool = True):
+        """Host side of a (captured) step: advance the step count and copy this step's constants to the device buffer.
+        advance=False stages the constants of the NEXT step without counting it (used while capturing: nothing executes)."""
+        if advance:
+            self.steps += 1
+        self._hyper_host = ops.adamw_hyper(self.steps if advance else self.steps + 1, self.lr, self.betas, self.eps,
+                                           self.weight_decay, grad_scale)
+        self.hyper_dev.copy_(self._hyper_host, non_blocking=True)
+
+    def step_dev(self):
+        """Device side: the update with constants from `hyper_dev` (what gets captured)."""
+        ops.adamw_step_dev(self.param, self.grad, self.exp_avg, self.exp_avg_sq, self.hyper_dev)
+
     def scheduler_step(self, iter_max: int, power: float = 0.9, min_lr: float = 1e-5):
         self.sched_it += 1
         self.lr = polynomial_lr(self.base_lr, self.lr, self.sched_it, iter_max, power, min_lr)
@@ -113,3 +130,53 @@ def build_optimizers(encoder, decoder, lr_cnn: float, lr: float, lr_cva: Optiona
     if g["cva"]:
         opts["cva"] = FlatAdamW(g["cva"], lr_cva if lr_cva is not None else lr_cnn, weight_decay)
     return opts
+
+
+class GraphedTrainStep:
+    """One training step (taped forward, mask loss, backward, AdamW on every group, gradient reset) captured into a hipGraph
+    and replayed: at config 5's micro-batch the eager step is bound by ~10^4 host-side launches, not by the GPU.
+    `forward_fn(x) -> logits` must be built from mumpy_hip.autograd functions (capture-safe: no host synchronisation).
+    Stochastic depth must be off (a captured mask would repeat).  Learning-rate schedules keep working: the AdamW constants
+    are staged into device memory before each replay.  Call `step(x, target)` -> loss3 (device tensor [total, iou, focal])."""
+
+    def __init__(self, forward_fn, optimizers, x, target, warmup: int = 3, loss_scale: float = 1.0):
+        self.opts = list(optimizers.values()) if isinstance(optimizers, dict) else list(optimizers)
+        self.x, self.target = x.clone(), target.clone()
+        for o in self.opts:
+            o.enable_device_hyper()
+
+        def body():
+            logits = forward_fn(self.x)
+            loss3, dlogits = ops.mask_loss(logits.detach(), self.target, loss_scale=loss_scale)
+            logits.backward(dlogits)
+            for o in self.opts:
+                o.step_dev()
+                o.zero_grad()
+            return loss3
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                      # warm-up steps are real steps (caches, allocator, lazy inits)
+                for o in self.opts:
+                    o.stage_hyper()
+                body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        for o in self.opts:
+            o.stage_hyper(advance=False)                 # capture records the launches; it does not run a step
+        with torch.cuda.graph(self.graph):
+            self.loss3 = body()
+        bump_weights_epoch()
+
+    def step(self, x=None, target=None, grad_scale: float = 1.0):
+        if x is not None:
+            self.x.copy_(x)
+        if target is not None:
+            self.target.copy_(target)
+        for o in self.opts:
+            o.stage_hyper(grad_scale)
+        self.graph.replay()
+        bump_weights_epoch()
+        return self.loss3

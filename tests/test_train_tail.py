@@ -241,3 +241,39 @@ def test_two_rank_training_step_matches_accumulated_single_process():
         swin_block_train(blk, seeded_randn(300 + rank, 2, 196, 96).to(dev)).backward(seeded_randn(310 + rank, 2, 196, 96).to(dev))
     opt.step(grad_scale=0.5)
     assert rel_err(res[0], opt.param.cpu()) < 1e-6
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_equals_eager_steps():
+    """GraphedTrainStep (hipGraph replay of forward + loss + backward + AdamW, step constants staged in device memory) walks the
+    same parameter trajectory as eager steps, learning-rate changes included."""
+    from weight_fill import fill_module_
+    from models.decoder.decoder import BaselineDecoder
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import baseline_decoder_train
+    from mumpy_hip.train import FlatAdamW, GraphedTrainStep
+    dev = torch.device("cuda:0")
+    x = seeded_randn(400, 2, 64, 7, 7).to(dev)
+    target = (seeded_randn(401, 2, 1, 224, 224) > 1.0).float().to(dev)
+    lrs = [1e-3, 1e-3, 1e-3, 5e-4, 2.5e-4, 1e-4]
+
+    def make():
+        dec = fill_module_(BaselineDecoder(in_channels=64, features=[128] * 5)).eval().to(dev)
+        return dec, FlatAdamW(dec.parameters(), lr=lrs[0], weight_decay=1e-4)
+    dec_e, opt_e = make()
+    for lr in lrs:                                                        # eager reference trajectory
+        opt_e.lr = lr
+        logits = baseline_decoder_train(dec_e, x)
+        loss3, dl = ops.mask_loss(logits.detach(), target)
+        logits.backward(dl)
+        opt_e.step()
+        opt_e.zero_grad()
+    dec_g, opt_g = make()
+    gs = GraphedTrainStep(lambda xx: baseline_decoder_train(dec_g, xx), [opt_g], x, target, warmup=3)   # 3 real steps at lrs[0..2]
+    for lr in lrs[3:]:
+        opt_g.lr = lr
+        gs.step()
+    torch.cuda.synchronize()
+    assert opt_g.steps == opt_e.steps == len(lrs)
+    assert rel_err(opt_g.param.cpu(), opt_e.param.cpu()) < 1e-5
+    assert rel_err(opt_g.exp_avg_sq.cpu(), opt_e.exp_avg_sq.cpu()) < 1e-4
