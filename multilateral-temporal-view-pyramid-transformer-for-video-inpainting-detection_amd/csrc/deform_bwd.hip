@@ -166,7 +166,13 @@ extern "C" int mumpy_dwconv5_window_fwd(const float* x, const float* w, const fl
     if (N == 0) return 0;
     MUMPY_REQUIRE(x && w && b && u, MUMPY_ENULL, "dwconv5: null pointer");
     MUMPY_REQUIRE(N > 0 && N < (1ll << 31) && C > 0 && C <= 384, MUMPY_EINVAL, "dwconv5: bad shape (C=%d)", C);
-    hipLaunchKernelGGL(dwconv5_fwd_kernel, dim3((unsigned)N), dim3(256), WT * C * sizeof(float), as_stream(stream), x, w, b, u, C);
+    const size_t lds = WT * C * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv5_fwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MUMPY_REQUIRE(e == hipSuccess, (int)e, "dwconv5: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(dwconv5_fwd_kernel, dim3((unsigned)N), dim3(256), lds, as_stream(stream), x, w, b, u, C);
     MUMPY_CHECK_LAUNCH("dwconv5_fwd");
     return 0;
 }
@@ -181,8 +187,13 @@ extern "C" int mumpy_dwconv5_window_bwd(const float* x, const float* w, const fl
     MUMPY_REQUIRE(N > 0 && N < (1ll << 31) && C > 0 && C <= 384, MUMPY_EINVAL, "dwconv5_bwd: bad shape (C=%d)", C);
     MUMPY_REQUIRE(workspace_bytes >= mumpy_dwconv5_window_bwd_workspace_bytes(N, C), MUMPY_EINVAL, "dwconv5_bwd: workspace too small");
     float* part = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(dwconv5_bwd_kernel, dim3((unsigned)N), dim3(256), 2 * WT * C * sizeof(float), as_stream(stream), x, w, du, dx,
-                       part, C);
+    const size_t lds = 2 * WT * C * sizeof(float);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv5_bwd_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        MUMPY_REQUIRE(e == hipSuccess, (int)e, "dwconv5_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(dwconv5_bwd_kernel, dim3((unsigned)N), dim3(256), lds, as_stream(stream), x, w, du, dx, part, C);
     MUMPY_CHECK_LAUNCH("dwconv5_bwd");
     // part rows are [tap 0..24][C] then [bias][C]; dw is (C, 25) like the module's (C,1,5,5) weight: reduce to a (26, C) image,
     // the caller transposes the first 25 rows (mumpy_hip/autograd.py)
