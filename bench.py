@@ -55,8 +55,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (micro-batch)")
     ap.add_argument("--frames", type=int, default=5)
-    ap.add_argument("--math", choices=["fp32", "bf16"], default="fp32",
-                    help="matrix arithmetic of the GEMMs/convolutions: fp32 (headline, default) or bf16 operands + fp32 accumulate")
+    ap.add_argument("--math", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+                    help="matrix arithmetic of the GEMMs/convolutions: fp32 on the fp32 MFMA (headline, default), bf16x3 = fp32 "
+                         "products from three bf16 pieces per operand on the bf16 MFMA (fp32-level accuracy), bf16 = bf16 "
+                         "operands + fp32 accumulate")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement reported beside the fp32 headline")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
@@ -269,7 +272,8 @@ def main():
             "metric": "clips/sec fwd (B=8,T=5,224x224)", "value": round(clips / dt, 3), "unit": "clips/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.math == "fp32" else "bf16 matrix operands, f32 accumulate and storage", "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16x3": "f32 (matrix products from 3 bf16 pieces per operand on the bf16 MFMA, f32 accumulate)",
+                      "bf16": "bf16 matrix operands, f32 accumulate and storage"}[args.math], "data": "synthetic",
             "config": {"workload": f"full Mumpy forward (3 temporal views, pyramid decoder), B={args.batch} clips/GPU, "
                                    f"T={args.frames}, 224x224, fp32, tubelets ({args.frames},{args.frames - 1},1)",
                        "global_batch": args.batch * world, "launch": ("eager" if fwd is None else "hipGraph replay") + ", fork/join over HIP streams (independent branches co-scheduled)",
@@ -283,6 +287,28 @@ def main():
             "serial_eager_forward_ms": round(eager_ms, 3),
             "eval_metric": {"f1": float(metric[0] / metric[2]), "iou": float(metric[1] / metric[2]), "clips": int(metric[2])},
         }
+        if args.math == "fp32" and world == 1 and not args.no_alt:
+            # the same workload with the GEMMs / convolutions in split-precision mode (fp32-level accuracy, tests:
+            # test_linear_bf16x3_math, test_full_model_bf16x3_math_t5): reported beside the headline, never as `value`
+            log("alt: bf16x3 matrix math")
+            ops.set_matrix_math("bf16x3")
+            with torch.no_grad():
+                fused_forward(enc, dec, x, with_mask=True)
+            fwd3 = None if args.no_graph else GraphedForward(enc, dec, x, with_mask=True)
+            run3 = (lambda: fused_forward(enc, dec, x, with_mask=True)[1]) if fwd3 is None else (lambda: fwd3(x)[1])
+            for _ in range(2):
+                run3()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                mask3 = run3()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t3
+            ops.set_matrix_math("fp32")
+            out["alt_bf16x3"] = {"math": "fp32 products as 6 bf16 piece products (3 pieces per operand), f32 accumulate",
+                                 "value": round(args.batch * args.steps / dt3, 3), "unit": "clips/s",
+                                 "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                                 "mask_pixels_differing_from_fp32_path": int((mask3 != mask).sum())}
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores)")
             out["cpu_baseline"] = cpu_baseline(args.frames, args.cpu_sample_batch)

@@ -40,6 +40,11 @@ extern "C" {
  * MFMA (fp32 accumulate, fp32 bias/activation/residual, fp32 tensors in memory).  Config 3's matrix arithmetic; the
  * default (flag absent) is exact fp32 on v_mfma_f32_32x32x2_f32. */
 #define MUMPY_MATH_BF16 0x100
+/* OR-ed into `act` likewise (exclusive with MUMPY_MATH_BF16): fp32 products on the bf16 matrix pipe.  Each fp32 operand is
+ * split while staged into three bf16 pieces (24+ mantissa bits kept) and the six piece products of weight >= 2^-16 are
+ * accumulated in fp32; the dropped terms are <= 2^-24 |a||b|, one fp32 rounding.  fp32-level accuracy at 6/16 of the
+ * fp32 MFMA time.  Operands outside bf16's exponent handling (inf, NaN, |v| < 2^-110) are not split faithfully. */
+#define MUMPY_MATH_BF16X3 0x200
 
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);

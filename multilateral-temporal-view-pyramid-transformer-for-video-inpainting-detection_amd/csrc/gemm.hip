@@ -362,11 +362,22 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
 // applied to the GEMMs and convolutions only; it turns them from MFMA-bound into staging/HBM-bound.
 // LDS rows hold 32 bf16 (16 dwords) padded to 20 dwords: conflict-free ds_read_b128 (one 8-element fragment per lane
 // per 16-deep MFMA step).  Same tiles / planner / split-K / implicit-GEMM addressing as the fp32 kernel.
+//
+// SPLIT-PRECISION mode (MUMPY_MATH_BF16X3, NP = 3): fp32 products on the bf16 matrix pipe.  Each fp32 operand is split
+// while being staged into three bf16 pieces, v = p0 + p1 + p2 with p0 = bf16(v), p1 = bf16(v - p0), p2 = bf16(v - p0 - p1)
+// (round-to-nearest-even; both subtractions are exact in fp32), i.e. 24+ mantissa bits are kept, and the product is
+// accumulated in fp32 from the six piece products of weight >= 2^-16: a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0), small
+// terms first.  The three dropped products are <= 2^-24 |a||b| each -- the size of ONE fp32 rounding -- so the result
+// carries fp32-level error (measured against an fp64 product: same max / rms error as the v_mfma_f32_32x32x2_f32
+// kernel, tests/test_hip_parity.py::test_linear_bf16x3_math) at 6/16 of the fp32 MFMA time.  Each piece has its own LDS
+// plane [piece][row][LDH]; the wide tile keeps ONE LDS buffer (three planes x 256 rows = 60 KB, two blocks per CU)
+// and refills it between two barriers while the other resident block's MFMAs run.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int LDH = 20;
 
-template <int BM, int BN, int WM, int WN, bool CONV>
+template <int BM, int BN, int WM, int WN, bool CONV, int NP = 1, int NBUF = 2>
 __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* residual,
                                                             float* Y, int64_t M, int N, int K, int act, unsigned gn,
@@ -376,7 +387,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
     constexpr int WAVES_N = BN / WN;
     static_assert((BM / WM) * (BN / WN) == 4, "4 waves per block");
     constexpr int RPI = 32, A_LD = BM / RPI, B_LD = BN / RPI;
-    __shared__ __attribute__((aligned(16))) uint32_t lds[2][(BM + BN) * LDH];
+    constexpr int PL = (BM + BN) * LDH;              // dwords per piece plane
+    static_assert(NBUF * NP * PL * 4 <= 65536, "LDS tile exceeds the static limit");
+    __shared__ __attribute__((aligned(16))) uint32_t lds[NBUF][NP * PL];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -445,17 +458,23 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
     };
-    auto pack = [](const f32x4& v) -> uint2 {
-        bf16x4 b = {(__bf16)v.x, (__bf16)v.y, (__bf16)v.z, (__bf16)v.w};
-        return *reinterpret_cast<uint2*>(&b);
+    // piece p of the split: RNE to bf16 (v_cvt_pk_bf16_f32), the remainder (exact in fp32) goes on to the next piece
+    auto lstore_row = [&](uint32_t* dst, f32x4 r) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const bf16x2 lo = __builtin_convertvector(f32x2{r.x, r.y}, bf16x2), hi = __builtin_convertvector(f32x2{r.z, r.w}, bf16x2);
+            const uint2 u = {*reinterpret_cast<const uint32_t*>(&lo), *reinterpret_cast<const uint32_t*>(&hi)};
+            *reinterpret_cast<uint2*>(dst + p * PL) = u;
+            if (p + 1 < NP)
+                r -= f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u)};
+        }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            *reinterpret_cast<uint2*>(&lds[buf][(ld_row + RPI * i) * LDH + 2 * ld_c4]) = pack(areg[i]);
+        for (int i = 0; i < A_LD; ++i) lstore_row(&lds[buf][(ld_row + RPI * i) * LDH + 2 * ld_c4], areg[i]);
 #pragma unroll
-        for (int i = 0; i < B_LD; ++i)
-            *reinterpret_cast<uint2*>(&lds[buf][(BM + ld_row + RPI * i) * LDH + 2 * ld_c4]) = pack(breg[i]);
+        for (int i = 0; i < B_LD; ++i) lstore_row(&lds[buf][(BM + ld_row + RPI * i) * LDH + 2 * ld_c4], breg[i]);
     };
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -464,33 +483,74 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // piece products, smallest weight first: (a2 b0) (a0 b2) (a1 b1) | (a1 b0) (a0 b1) | (a0 b0)
+    constexpr int NPROD = (NP == 3) ? 6 : 1;
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
     const int nk = K / ksplit / BK;
-    gload(kbeg);
-    lstore(0);
-    __syncthreads();
-    for (int kc = 0; kc < nk; ++kc) {
-        const int buf = kc & 1;
-        if (kc + 1 < nk) gload(kbeg + (kc + 1) * BK);
-        bf16x8 af[TM][2], bf[TN][2];
+    bf16x8 af[TM][2][NP], bf[TN][2][NP];
+    auto fread = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int st = 0; st < 2; ++st)      // MFMA step st: k = 16 st + 8 h + j (A/B operand maps of 32x32x16 bf16)
-                af[i][st] = *reinterpret_cast<const bf16x8*>(&lds[buf][(wm * WM + 32 * i + c) * LDH + 8 * st + 4 * h]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    af[i][st][p] = *reinterpret_cast<const bf16x8*>(&lds[buf][p * PL + (wm * WM + 32 * i + c) * LDH + 8 * st + 4 * h]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int st = 0; st < 2; ++st)
-                bf[j][st] = *reinterpret_cast<const bf16x8*>(&lds[buf][(BM + wn * WN + 32 * j + c) * LDH + 8 * st + 4 * h]);
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    bf[j][st][p] = *reinterpret_cast<const bf16x8*>(&lds[buf][p * PL + (BM + wn * WN + 32 * j + c) * LDH + 8 * st + 4 * h]);
+    };
+    auto mma = [&]() {
 #pragma unroll
         for (int st = 0; st < 2; ++st)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int q = 0; q < NPROD; ++q)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st], bf[j][st], acc[i][j], 0, 0, 0);
-        if (kc + 1 < nk) lstore(buf ^ 1);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st][NP == 3 ? PA[q] : 0],
+                                                                            bf[j][st][NP == 3 ? PB[q] : 0], acc[i][j], 0, 0, 0);
+    };
+    const int klast = kbeg + (nk - 1) * BK;
+    if (NBUF == 2) {
+        // chunk k+1 is loaded under chunk k's MFMAs and split into the other LDS buffer after them (one barrier per chunk)
+        gload(kbeg);
+        lstore(0);
         __syncthreads();
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            gload(kbeg + (kc + 1) * BK);
+            fread(kc & 1);
+            mma();
+            lstore((kc & 1) ^ 1);
+            __syncthreads();
+        }
+        fread((nk - 1) & 1);
+        mma();
+    } else {
+        // One LDS buffer; the staging registers run a chunk further ahead.  Per chunk: read chunk k's fragments | barrier |
+        // split chunk k+1 (loaded an iteration ago) into the buffer, issue chunk k+2's loads, chunk k's MFMAs | barrier.
+        // Split VALU, LDS writes and MFMAs sit in ONE basic block (the last chunk is peeled, loads past the end are
+        // clamped to the last chunk instead of predicated) so they interleave: the split hides under the matrix pipe.
+        gload(kbeg);
+        lstore(0);
+        gload(nk > 1 ? kbeg + BK : kbeg);
+        __syncthreads();
+        for (int kc = 0; kc + 1 < nk; ++kc) {
+            fread(0);
+            __syncthreads();                     // every wave holds chunk kc in registers: the buffer may be refilled
+            lstore(0);
+            const int knext = kbeg + (kc + 2) * BK;
+            gload(knext < klast ? knext : klast);
+            mma();
+            __syncthreads();
+        }
+        fread(0);
+        mma();
     }
     store_tile<TM, TN, WM, WN>(acc, m0, n0, wm, wn, c, h, M, N, bias, residual, Y, act, ksplit, ks, slab);
 }
@@ -528,8 +588,34 @@ struct Plan {
 // prologue/epilogue.  When even the 64-tile grid leaves CUs idle and K is deep, K is split (slices >= 384).
 constexpr int NUM_CU = 256;
 
-Plan make_plan(int64_t M, int N, int K, bool allow_split) {
+// Split-precision (bf16x3) kernels, fitted to the same sweep (gpurun tools/gemm_shapes.py with MUMPY_MATH=bf16x3 and
+// MUMPY_GEMM_FORCE): the 128x128 tile (two co-resident blocks per CU = 512 slots) wins whenever K-splitting can bring its
+// grid to ~half the slots or more; below that the 64x64 tile (LDS-bound at three planes per operand) is the lesser evil.
+Plan make_plan_x3(int64_t M, int N, int K, bool allow_split) {
+    Plan p;
+    const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
+    const unsigned gn128 = (N + 127) / 128, gn64 = (N + 63) / 64;
+    const int64_t b128 = gm128 * gn128, b64 = gm64 * gn64;
+    auto fit = [&](int ks) {                         // largest split <= ks with slices >= 384 deep and whole chunks
+        if (!allow_split) return 1;
+        if (ks > K / 384) ks = K / 384;
+        if (ks > 16) ks = 16;
+        while (ks > 1 && (K % (32 * ks)) != 0) --ks;
+        return ks < 1 ? 1 : ks;
+    };
+    const int ksw = fit((int)((448 + b128 / 2) / b128));
+    if (b128 * ksw >= 240) {
+        p.tile = 0; p.ksplit = ksw; p.gm = gm128; p.gn = gn128;
+    } else {
+        p.tile = 2; p.ksplit = (b64 < 2 * 256 && K >= 768) ? fit((int)((3 * 256 + b64 - 1) / b64)) : 1;
+        p.gm = gm64; p.gn = gn64;
+    }
+    return p;
+}
+
+Plan make_plan(int64_t M, int N, int K, bool allow_split, bool x3 = false) {
     static const char* force = getenv("MUMPY_GEMM_FORCE");      // tuning hook: "tile,ksplit"
+    if (x3 && !force) return make_plan_x3(M, N, K, allow_split);
     Plan p;
     const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
     const unsigned gn128 = (N + 127) / 128, gn64 = (N + 63) / 64;
@@ -570,8 +656,9 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     if (rpb <= 0) { rpb = M; bstride = 0; }
     const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
     const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
+    const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0;
     act &= 0xff;
-    Plan p = make_plan(M, N, K, ws != nullptr);
+    Plan p = make_plan(M, N, K, ws != nullptr, math_x3);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
@@ -586,7 +673,17 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
                        ws, rpb, bstride, dbgmask, cg)
     static const int dbgmask = getenv("MUMPY_GEMM_DBG") ? atoi(getenv("MUMPY_GEMM_DBG")) : 0;
     static const bool use_glds = getenv("MUMPY_GEMM_GLDS") ? atoi(getenv("MUMPY_GEMM_GLDS")) != 0 : false;
-    if (math_bf16) {
+    if (math_x3) {
+        const bool wide = (p.tile == 0 || p.tile == 3);
+#define MUMPY_GEMM_X3(BM_, BN_, WM_, WN_, CV_, NB_)                                                                    \
+    hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, CV_, 3, NB_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, \
+                       bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, cg)
+        if (wide && conv) MUMPY_GEMM_X3(128, 128, 64, 64, true, 1);
+        else if (wide) MUMPY_GEMM_X3(128, 128, 64, 64, false, 1);
+        else if (conv) MUMPY_GEMM_X3(64, 64, 32, 32, true, 2);
+        else MUMPY_GEMM_X3(64, 64, 32, 32, false, 2);
+#undef MUMPY_GEMM_X3
+    } else if (math_bf16) {
         const bool wide = (p.tile == 0 || p.tile == 3);
 #define MUMPY_GEMM_H(BM_, BN_, WM_, WN_, CV_)                                                                          \
     hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, CV_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, bias,   \
@@ -637,7 +734,9 @@ static int check_linear_args(const float* x, const float* W, const float* residu
     MUMPY_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, MUMPY_EINVAL,
                   "linear: need K %% 32 == 0 and N %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
     MUMPY_REQUIRE((act & 0xff) == MUMPY_ACT_NONE || (act & 0xff) == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear: unknown act %d", act);
-    MUMPY_REQUIRE((act & ~(0xff | MUMPY_MATH_BF16)) == 0, MUMPY_EINVAL, "linear: unknown flag bits in act 0x%x", act);
+    MUMPY_REQUIRE((act & ~(0xff | MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3)) == 0, MUMPY_EINVAL, "linear: unknown flag bits in act 0x%x", act);
+    MUMPY_REQUIRE((act & (MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3)) != (MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3), MUMPY_EINVAL,
+                  "linear: MUMPY_MATH_BF16 and MUMPY_MATH_BF16X3 are exclusive");
     return 0;
 }
 
@@ -650,8 +749,9 @@ extern "C" int mumpy_linear_fwd(const float* x, const float* W, const float* bia
 
 extern "C" int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
-    const Plan p = make_plan(M, N, K, true);
-    return p.ksplit > 1 ? (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) : 0;
+    const Plan p = make_plan(M, N, K, true), q = make_plan(M, N, K, true, true);     // either matrix-math mode
+    const int ks = p.ksplit > q.ksplit ? p.ksplit : q.ksplit;
+    return ks > 1 ? (int64_t)ks * M * N * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,

@@ -8,7 +8,7 @@ import torch
 from .lib import load_library
 
 ACT_NONE, ACT_GELU = 0, 1
-MATH_FP32, MATH_BF16 = 0, 0x100
+MATH_FP32, MATH_BF16, MATH_BF16X3 = 0, 0x100, 0x200
 _MATH = MATH_FP32          # OR-ed into the `act` argument of every linear / conv launch
 _WS_BYTES = {}
 
@@ -16,15 +16,20 @@ _WS_BYTES = {}
 def set_matrix_math(mode: str) -> None:
     """"fp32" (default): exact fp32 products on v_mfma_f32_32x32x2_f32.  "bf16": operands of every GEMM / convolution are
     rounded to bf16 while being staged and multiplied on the bf16 MFMA with fp32 accumulation (config 3's arithmetic);
-    tensors in memory, LayerNorm / softmax / GroupNorm statistics and all other kernels stay fp32."""
+    tensors in memory, LayerNorm / softmax / GroupNorm statistics and all other kernels stay fp32.
+    "bf16x3": fp32 products on the bf16 matrix pipe -- each operand is split into three bf16 pieces while staged and the
+    six significant piece products are accumulated in fp32; fp32-level accuracy (see include/mumpy_hip.h)."""
     global _MATH
-    if mode not in ("fp32", "bf16"):
+    if mode not in _MODES:
         raise ValueError(f"unknown matrix math mode {mode!r}")
-    _MATH = MATH_BF16 if mode == "bf16" else MATH_FP32
+    _MATH = _MODES[mode]
+
+
+_MODES = {"fp32": MATH_FP32, "bf16": MATH_BF16, "bf16x3": MATH_BF16X3}
 
 
 def matrix_math() -> str:
-    return "bf16" if _MATH == MATH_BF16 else "fp32"
+    return {v: k for k, v in _MODES.items()}[_MATH]
 NEG = -1e30
 
 

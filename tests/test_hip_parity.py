@@ -559,6 +559,71 @@ def test_full_model_bf16_math_t5(full_golden, bf16_math):
     assert float(ref[flipped].abs().max()) <= float((logits - ref).abs().max())
 
 
+# ------------------------------------------------------------------ split-precision mode: fp32 products on the bf16 pipe
+@pytest.fixture
+def bf16x3_math():
+    ops.set_matrix_math("bf16x3")
+    yield
+    ops.set_matrix_math("fp32")
+
+
+@pytest.mark.parametrize("m,n,k", [(300, 128, 96), (1568, 384, 1536), (7840, 512, 2048), (7840, 2048, 512), (392, 256, 12800),
+                                   (25088, 96, 384), (1960, 768, 3072)])
+def test_linear_bf16x3_math(m, n, k):
+    """Three bf16 pieces per operand, six piece products, fp32 accumulate: the result must be as close to the fp64
+    product as the native fp32-MFMA kernel is (same inputs, max and rms error compared), i.e. this is fp32 arithmetic
+    carried out on the bf16 matrix pipe, not a reduced-precision mode.  Shapes cover both tiles and the K-split plans."""
+    x, w, b = seeded_randn(m, m, k), seeded_randn(n, n, k) / k ** 0.5, seeded_randn(k, n)
+    r = seeded_randn(7, m, n)
+    ref = F.gelu(F.linear(x.double(), w.double(), b.double())) + r.double()
+    y32 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=ops.ACT_GELU, residual=r.to(DEV)).cpu().double()
+    ops.set_matrix_math("bf16x3")
+    try:
+        y3 = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV), act=ops.ACT_GELU, residual=r.to(DEV)).cpu().double()
+    finally:
+        ops.set_matrix_math("fp32")
+    e32, e3 = (y32 - ref).abs(), (y3 - ref).abs()
+    print(f"{m}x{n}x{k}: fp32 MFMA max {e32.max():.2e} rms {e32.pow(2).mean().sqrt():.2e} | bf16x3 max {e3.max():.2e} rms {e3.pow(2).mean().sqrt():.2e}")
+    assert float(e3.max()) <= 1.5 * float(e32.max()) + 1e-7
+    assert float(e3.pow(2).mean().sqrt()) <= 1.25 * float(e32.pow(2).mean().sqrt()) + 1e-8
+    assert rel_err(y3.float(), ref.float()) < 2e-6
+
+
+def test_linear_bf16x3_dynamic_range(bf16x3_math):
+    """Operands spanning 2^-40 .. 2^40 in magnitude (per-row / per-column scales): the split keeps 24 bits at every scale."""
+    m, n, k = 512, 256, 256
+    x = seeded_randn(1, m, k) * torch.exp2(torch.linspace(-40, 40, m)).unsqueeze(1)
+    w = seeded_randn(2, n, k) * torch.exp2(torch.linspace(-20, 20, n)).unsqueeze(1)
+    y = ops.linear(x.to(DEV), w.to(DEV)).cpu().double()
+    ref = x.double() @ w.double().t()
+    scale = (x.double().abs() @ w.double().abs().t())                    # the rounding-error scale of each output
+    assert float(((y - ref).abs() / scale).max()) < 4e-7
+
+
+def test_conv2d_bf16x3_math(bf16x3_math):
+    x = seeded_randn(5, 2, 128, 28, 28)
+    w = seeded_randn(6, 128, 128, 3, 3) / (128 * 9) ** 0.5
+    y = ops.conv2d_nhwc(x.to(DEV).contiguous(memory_format=torch.channels_last), w.permute(0, 2, 3, 1).contiguous().to(DEV)).cpu()
+    assert rel_err(y, F.conv2d(x.double(), w.double(), padding=1).float()) < 2e-6
+
+
+def test_full_model_bf16x3_math_t5(full_golden, bf16x3_math):
+    """Whole model (B=1, T=5) with every GEMM / convolution in split-precision mode against the reference's fp32 golden:
+    the SAME 1e-3 bar as the native fp32 path (north_star), and in practice the same ~1e-5 distance."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = golden_input(full_golden, "b1t5/x").to(DEV)
+    with torch.no_grad():
+        logits = dec(*enc(x))[0].cpu()
+    ref = torch.tensor(full_golden["b1t5/logits"])
+    err = rel_err(logits, ref)
+    print(f"bf16x3 matrix math: logits rel err {err:.3e}")
+    assert err < 1e-4
+    assert bool((O.mask_from_logits(logits) == O.mask_from_logits(ref)).all()) or err < 1e-5
+
+
 def test_strict_checkpoint_roundtrip(tmp_path, model_t3):
     """a reference-format checkpoint (encoder_{e}.pt = plain state_dict) loads strictly and reproduces
     the outputs; 'module.'-prefixed (DataParallel) checkpoints are what utils/utils.py:156-176 strips."""

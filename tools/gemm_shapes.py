@@ -37,6 +37,8 @@ def model_shapes(B=8, T=5):
 def main():
     dev = torch.device("cuda:0")
     tile = int(os.environ.get("MUMPY_GEMM_TILE", "0"))
+    ops.set_matrix_math(os.environ.get("MUMPY_MATH", "fp32"))       # fp32 | bf16 | bf16x3
+    check = os.environ.get("MUMPY_GEMM_CHECK", "0") != "0"           # max / rms error against an fp64 product
     tot_t = tot_f = 0.0
     rows = []
     for (m, n, k), (cnt, tag) in sorted(model_shapes().items(), key=lambda kv: -kv[0][0] * kv[0][1] * kv[0][2] * kv[1][0]):
@@ -51,11 +53,17 @@ def main():
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / reps
         fl = 2.0 * m * n * k
-        rows.append((tag, m, n, k, cnt, us, fl / us / 1e6, cnt * us / 1e3))
+        err = ""
+        if check:
+            mm = min(m, 2048)
+            ref = x[:mm].double() @ w.double().t() + b.double()
+            d = (ops.linear(x, w, b)[:mm].double() - ref)
+            err = f"  max {d.abs().max().item():.2e} rms {d.pow(2).mean().sqrt().item():.2e} (ref rms {ref.pow(2).mean().sqrt().item():.2f})"
+        rows.append((tag, m, n, k, cnt, us, fl / us / 1e6, cnt * us / 1e3, err))
         tot_t += cnt * us / 1e3; tot_f += cnt * fl
     print(f"{'shape':18s} {'M':>7s} {'N':>5s} {'K':>6s} {'cnt':>3s} {'us':>8s} {'TF':>6s} {'ms tot':>7s}")
     for r in rows:
-        print(f"{r[0]:18s} {r[1]:7d} {r[2]:5d} {r[3]:6d} {r[4]:3d} {r[5]:8.1f} {r[6]:6.1f} {r[7]:7.2f}")
+        print(f"{r[0]:18s} {r[1]:7d} {r[2]:5d} {r[3]:6d} {r[4]:3d} {r[5]:8.1f} {r[6]:6.1f} {r[7]:7.2f}{r[8]}")
     print(f"TOTAL {tot_t:.2f} ms, {tot_f/1e9:.1f} GFLOP, {tot_f/tot_t/1e9:.1f} TF average")
 
 
