@@ -264,7 +264,16 @@ def main():
         log(f"timed: {1e3 * dt / args.steps:.2f} ms/step; profiling kernels")
         kernels, eager_ms = profile_kernels(enc, dec, x)
         dom = dict(kernels[0])
+        # HBM-side bytes per launch of the dominant entry point from the PMC passes of the same workload (FETCH_SIZE x2 +
+        # WRITE_SIZE; tools/pmc_bench.sh + tools/summarize_pmc_bench.py -> profiles/): bench.py cannot run rocprofv3 on itself
         dom["traffic"] = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+            if args.math == "fp32" and args.batch == 8 and args.frames == 5 and dom["kernel"] in pmc:
+                dom["traffic"] = pmc[dom["kernel"]]["hbm_bytes_per_launch"]
+                dom["traffic_unit"] = "B per launch (PMC: profiles/r01_pmc_bench_traffic.md)"
+        except OSError:
+            pass
         dom.pop("launches", None)
         dom.pop("ms", None)
         clips = args.batch * world * args.steps
