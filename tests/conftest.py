@@ -32,6 +32,12 @@ def full_golden():
 
 
 @pytest.fixture(scope="session")
+def full_golden_t9():
+    """B=1, T=9 (config 4's temporal length at 224x224) from the real reference: tests/golden/gen_goldens_t9.py."""
+    return np.load(os.path.join(GOLDEN, "full_model_t9.npz"))
+
+
+@pytest.fixture(scope="session")
 def train_golden():
     return np.load(os.path.join(GOLDEN, "train_tail.npz"))
 

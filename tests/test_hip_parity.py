@@ -386,6 +386,20 @@ def test_full_model_t5(full_golden):
     _check_full(full_golden, "b1t5", logits.cpu(), feats.cpu(), fx.cpu(), vx, dx.cpu(), TOL)
 
 
+def test_full_model_t9(full_golden_t9):
+    """T = 9 at 224x224 (the long-temporal half of config 4) against the golden produced by the reference's own classes
+    with tubelets (9,8,1): logits, final features, every view tensor and the DCT bands."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=9), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 9]), DEV)
+    x = golden_input(full_golden_t9, "b1t9/x").to(DEV)
+    with torch.no_grad():
+        fx, vx, dx = enc(x)
+        logits, feats = dec(fx, vx, dx)
+    _check_full(full_golden_t9, "b1t9", logits.cpu(), feats.cpu(), fx.cpu(), vx, dx.cpu(), TOL)
+
+
 def test_full_model_t9_vs_oracle():
     """T = 9 (config 4's temporal length at 224x224, tubelets (9,8,1)): no reference golden, checked against the oracle
     (which is itself pinned at T=3 and T=5).  Exercises the long-tubelet tokenizer, r = 9 window aggregation in the

@@ -247,6 +247,16 @@ def test_full_model_t5(full_golden):
     _check_full(full_golden, "b1t5", *out, FULL_TOL)
 
 
+def test_full_model_b1t9(full_golden_t9):
+    """Config 4's temporal length at 224x224: tubelets (9,8,1), r = 9 window sums in the deformable attention, 9x9
+    temporal attention; golden from the reference's own classes (gen_goldens_t9.py)."""
+    enc_sd, dec_sd = _filled("state_dict_encoder_t9.json"), _filled("state_dict_decoder_t9.json")
+    x = golden_input(full_golden_t9, "b1t9/x")
+    with torch.no_grad():
+        out = O.full_forward(enc_sd, dec_sd, x)
+    _check_full(full_golden_t9, "b1t9", *out, FULL_TOL)
+
+
 def test_baseline_encoder(full_golden):
     sd = _filled("state_dict_baseline_encoder.json")
     with torch.no_grad():
