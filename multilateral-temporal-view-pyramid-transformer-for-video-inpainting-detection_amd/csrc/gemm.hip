@@ -372,6 +372,13 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
 // kernel, tests/test_hip_parity.py::test_linear_bf16x3_math) at 6/16 of the fp32 MFMA time.  Each piece has its own LDS
 // plane [piece][row][LDH]; the wide tile keeps ONE LDS buffer (three planes x 256 rows = 60 KB, two blocks per CU)
 // and refills it between two barriers while the other resident block's MFMAs run.
+// Measured (MI355X, M=8192 N=2048 K=512): 107 us = 160 TFLOP/s of fp32-equivalent work (the fp32-MFMA kernel: 181 us), i.e.
+// ~42 % of the bf16 matrix pipe's issue slots.  Tried without gain: (i) a software-pipelined form after the fp32 kernel
+// (16-deep chunks, two LDS buffers, fragment AND staging register double-buffering, one barrier per chunk, every phase in
+// one basic block so the scheduler interleaves split VALU / LDS / loads with the MFMA stream): 112 us; (ii) removing the
+// W-side split arithmetic altogether (an upper bound for pre-split weights): 108 us.  Two different structures and half
+// the VALU landing on one rate points at what they share -- the MFMA count at the clock the chip holds under bf16-MFMA
+// load plus the LDS bytes per MFMA (three planes per operand).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd")]
 from mumpy_hip import ops
 dev = torch.device("cuda:0")
+ops.set_matrix_math(os.environ.get("MUMPY_MATH", "fp32"))      # fp32 | bf16 | bf16x3 for the linear micro
 op, a = sys.argv[1], [int(v) for v in sys.argv[2:]]
 reps = int(os.environ.get("REPS", "20"))
 if op == "linear":

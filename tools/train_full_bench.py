@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """One training step of the full three-view model (Encoder + Decoder) on the HIP kernels: taped forward, mask loss, backward,
-fused AdamW over the cva / encoder / decoder groups (train.py:94-138).  usage: train_full_bench.py [batch] [frames] [--bf16] [--graph]
+fused AdamW over the cva / encoder / decoder groups (train.py:94-138).  usage: train_full_bench.py [batch] [frames] [--bf16 | --x3] [--graph]
+--x3: split-precision GEMMs / convolutions (fp32 products from three bf16 pieces per operand, fp32-level accuracy).
 --bf16: bf16-operand GEMMs / convolutions (fp32 accumulate, fp32 master weights, fp32 everything else) in forward and backward,
 i.e. config 5's matrix arithmetic; prints the gradient deviation from the fp32 step as well."""
 import os, sys, torch
@@ -15,6 +16,7 @@ from mumpy_hip.autograd import decoder_train, encoder_train
 from mumpy_hip.train import build_optimizers
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 BF16 = "--bf16" in sys.argv
+MODE = "bf16x3" if "--x3" in sys.argv else "bf16"
 B = int(args[0]) if args else 2
 T = int(args[1]) if len(args) > 1 else 5
 dev = torch.device("cuda:0")
@@ -31,7 +33,7 @@ def step():
     for o in opts.values():
         o.step(); o.zero_grad()
     return loss3
-if BF16:                                   # one step's flat encoder gradient in fp32 vs bf16 matrix math, same weights
+if BF16 or MODE == "bf16x3":                # one step's flat encoder gradient in fp32 vs bf16 matrix math, same weights
     def grads(mode):
         ops.set_matrix_math(mode)
         for o in opts.values():
@@ -40,8 +42,8 @@ if BF16:                                   # one step's flat encoder gradient in
         logits, _ = decoder_train(dec, fx, vx, dx)
         logits.backward(ops.mask_loss(logits.detach(), target)[1])
         return torch.cat([o.grad.clone() for o in opts.values()])
-    g32, g16 = grads("fp32"), grads("bf16")
-    print(f"bf16-math gradient vs fp32 gradient: relative L2 distance {float((g16 - g32).norm() / g32.norm()):.3e}, "
+    g32, g16 = grads("fp32"), grads(MODE)
+    print(f"{MODE}-math gradient vs fp32 gradient: relative L2 distance {float((g16 - g32).norm() / g32.norm()):.3e}, "
           f"cosine {float(torch.dot(g16, g32) / (g16.norm() * g32.norm())):.6f}")
     for o in opts.values():
         o.zero_grad()
@@ -77,5 +79,5 @@ with torch.no_grad():
     e1.record(); torch.cuda.synchronize()
 inf = e0.elapsed_time(e1) / n
 nparam = sum(p.numel() for p in list(enc.parameters()) + list(dec.parameters()))
-print(f"full model train step ({'bf16 matrix math' if BF16 else 'fp32'}), B={B}, T={T}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} clips/s ({nparam / 1e6:.1f} M parameters, groups {sorted(opts)}); "
+print(f"full model train step ({ops.matrix_math()} matrix math), B={B}, T={T}: {ms:.1f} ms/step = {B / ms * 1e3:.1f} clips/s ({nparam / 1e6:.1f} M parameters, groups {sorted(opts)}); "
       f"eager inference forward {inf:.1f} ms -> step / forward = {ms / inf:.2f}; loss over 5 steps {[round(l, 4) for l in losses]}")
