@@ -418,6 +418,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
     const int64_t m0 = (int64_t)tm * BM;
     const int n0 = (int)tn * BN;
     const int kbeg = ks * (K / ksplit);
+    // (Tried: lanes 8..15 of every 16-lane store group on row +4 instead of row +1, which makes the ds_write_b64 piece stores
+    // conflict-free at this 20-dword pitch -- SQ_LDS_BANK_CONFLICT 8.1 M -> 1.8 M cycles per launch -- with no change in the
+    // kernel's duration: the LDS is not what the waves wait on.)
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
     f32x4 areg[A_LD], breg[B_LD];
     const float* arow[A_LD];
@@ -531,6 +534,8 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         __syncthreads();
         for (int kc = 0; kc + 1 < nk; ++kc) {
             gload(kbeg + (kc + 1) * BK);
+            __builtin_amdgcn_sched_barrier(0);       // keep the loads at the top: hipcc otherwise sinks them below the MFMAs,
+                                                     // next to their use in lstore, and the wave waits out their whole latency
             fread(kc & 1);
             mma();
             lstore((kc & 1) ^ 1);
