@@ -30,6 +30,16 @@
 //     M=7840 N=512 K=2048, i.e. it TIES the kernels here on the large shapes (162 vs 159 us, 188 vs 186 us) and loses on
 //     small grids.  Structurally different kernels converging on the same rate says the limiter is the clock the chip
 //     holds under fp32-MFMA-plus-operand-traffic load, so the remaining lever is energy per MFMA (bytes moved per MFMA).
+//   * reference point (tools/gemm_shapes.py with MUMPY_COMPARE_TORCH=1): the vendor library's fp32 kernels (hipBLASLt via
+//     torch.addmm: Tensile MT256x256x32 / 128x128 macro tiles, 128x128 per wave, v_mfma_f32_16x16x4_f32, accumulators in
+//     AGPRs) run the large shapes at 117-140 TFLOP/s back to back, 1.15-1.35x this kernel (18.0 vs 20.8 ms over the model's
+//     shapes) -- so the 125-134 "ceiling" above is this kernel family's, not the chip's: a 128x128 wave tile reads a
+//     quarter of the LDS bytes per MFMA.  Two follow-ups, both negative: (i) this template instantiated as a 256x256 block of
+//     four 128x128 waves (LDS-DMA, 256 AGPRs + 256 VGPRs, one block per CU) is correct but no faster (172 us on M=7840 N=2048
+//     K=512 vs 177 here and 141 in the library): at one wave per SIMD every stall is exposed and hipcc's schedule is not
+//     the library's hand-placed one; (ii) swapping the library in for every large non-GELU GEMM of the forward (experiment
+//     through torch.addmm under the same hipGraph) moved the whole forward from 24.32 to 24.07 ms: in situ -- cold weights,
+//     co-scheduled branches, bias + residual no longer fused -- the isolated-kernel advantage does not carry over.
 #include <stdlib.h>
 #include "common.h"
 using namespace mumpy;

@@ -54,6 +54,16 @@ def main():
         us = e0.elapsed_time(e1) * 1e3 / reps
         fl = 2.0 * m * n * k
         err = ""
+        if os.environ.get("MUMPY_COMPARE_TORCH", "0") != "0":            # reference point only: torch's library GEMM (rocBLAS/hipBLASLt)
+            wt = w.t().contiguous()
+            for _ in range(3):
+                torch.addmm(b, x, wt)
+            e0.record()
+            for _ in range(reps):
+                torch.addmm(b, x, wt)
+            e1.record(); torch.cuda.synchronize()
+            ust = e0.elapsed_time(e1) * 1e3 / reps
+            err = f"  | torch.addmm {ust:8.1f} us {fl / ust / 1e6:6.1f} TF  ratio {us / ust:5.2f}"
         if check:
             mm = min(m, 2048)
             ref = x[:mm].double() @ w.double().t() + b.double()
