@@ -194,6 +194,16 @@ int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, f
 int mumpy_normalize_u8_fwd(const uint8_t* frames, float* out, int64_t nframes, int H, int W, const float* mean3,
                            const float* std3, void* stream);
 
+/* ---- the same with the loader's resize in front (universaldataset.py:75-79: PIL `img.resize(inputRes)` with the default
+ * filter of the pinned pillow==4.0.0, NEAREST): frames (nframes,Hs,Ws,3) uint8 -> out (nframes,3,H,W) fp32, out pixel (y,x) =
+ * source pixel (ytab[y], xtab[x]).  How non-224x224 footage (432x240, config 4) enters the model in the reference.
+ * ytab (H) / xtab (W) are DEVICE int32 tables holding Pillow's NEAREST source indices; build them on the host with
+ * mumpy_resize_nearest_table (Pillow's own double-accumulator walk, which decides exact ties) and upload.  W % 4 == 0. */
+int mumpy_resize_nearest_table(int src, int dst, int32_t* table_host);
+int mumpy_resize_normalize_u8_fwd(const uint8_t* frames, float* out, const int32_t* ytab, const int32_t* xtab,
+                                  int64_t nframes, int Hs, int Ws, int H, int W, const float* mean3, const float* std3,
+                                  void* stream);
+
 /* ---- out = a + b (n floats, n % 4 == 0): the residual add of CrossSwinBlock whose un-added operand is also
  *      consumed by the next view (mTVE:275-276).  out may alias a or b. */
 int mumpy_add_fwd(const float* a, const float* b, float* out, int64_t n, void* stream);

@@ -173,6 +173,71 @@ __global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __rest
 }
 }  // namespace
 
+// Same staging with the loader's resize in front (universaldataset.py:75-79: `img.resize(self.inputRes)` with no filter
+// argument; the reference pins pillow==4.0.0, whose default filter is NEAREST).  Pillow's NEAREST resize
+// (Geometry.c, ImagingScaleAffine) walks a double accumulator: xo = 0.5 * a; for each output x { xin = (int)xo; xo += a; }
+// with a = src / dst -- the ACCUMULATED value, not (x + 0.5) * a, decides exact-integer ties (1920 -> 224: x = 3 lands on
+// 30.0 or 29.999...), so the source-index tables are built on the host with exactly that loop (mumpy_resize_nearest_table)
+// and the kernel gathers through them.  How footage that is not 224x224 (432x240 DVI clips, config 4) enters the model.
+extern "C" int mumpy_resize_nearest_table(int src, int dst, int32_t* table_host) {
+    MUMPY_REQUIRE(table_host, MUMPY_ENULL, "resize_nearest_table: null pointer");
+    MUMPY_REQUIRE(src > 0 && dst > 0, MUMPY_EINVAL, "resize_nearest_table: bad sizes %d -> %d", src, dst);
+    const double a = (double)src / dst;
+    double xo = a * 0.5;
+    for (int x = 0; x < dst; ++x) {
+        int xin = xo < 0.0 ? -1 : (int)xo;
+        if (xin > src - 1) xin = src - 1;          // cannot happen for a pure scale; keeps the gather in bounds regardless
+        table_host[x] = xin;
+        xo += a;
+    }
+    return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void resize_normalize_u8_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst,
+                                                                  const int32_t* __restrict__ ytab, const int32_t* __restrict__ xtab,
+                                                                  int64_t nframes, int Hs, int Ws, int H, int W, float m0, float m1,
+                                                                  float m2, float s0, float s1, float s2) {
+    const int q4 = W >> 2;
+    const int64_t total = nframes * 3 * H * q4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int x4 = (int)(i % q4);
+        int64_t t = i / q4;
+        const int y = (int)(t % H); t /= H;
+        const int ch = (int)(t % 3);
+        const int64_t f = t / 3;
+        const float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2);
+        const float stdv = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
+        const uint8_t* row = src + ((f * Hs + ytab[y]) * (int64_t)Ws) * 3 + ch;
+        const int4 xi = *reinterpret_cast<const int4*>(xtab + 4 * x4);
+        f32x4 v;
+        v[0] = ((float)row[3 * (int64_t)xi.x] / 255.0f - mean) / stdv;
+        v[1] = ((float)row[3 * (int64_t)xi.y] / 255.0f - mean) / stdv;
+        v[2] = ((float)row[3 * (int64_t)xi.z] / 255.0f - mean) / stdv;
+        v[3] = ((float)row[3 * (int64_t)xi.w] / 255.0f - mean) / stdv;
+        *reinterpret_cast<f32x4*>(dst + ((f * 3 + ch) * H + y) * (int64_t)W + 4 * x4) = v;
+    }
+}
+}  // namespace
+
+extern "C" int mumpy_resize_normalize_u8_fwd(const uint8_t* frames, float* out, const int32_t* ytab, const int32_t* xtab,
+                                             int64_t nframes, int Hs, int Ws, int H, int W, const float* mean3,
+                                             const float* std3, void* stream) {
+    MUMPY_REQUIRE(frames && out && mean3 && std3 && ytab && xtab, MUMPY_ENULL, "resize_normalize_u8: null pointer");
+    MUMPY_REQUIRE(nframes >= 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0 && W % 4 == 0, MUMPY_EINVAL,
+                  "resize_normalize_u8: bad sizes %dx%d -> %dx%d (output width must be a multiple of 4)", Hs, Ws, H, W);
+    MUMPY_REQUIRE(aligned16(out) && aligned16(xtab), MUMPY_EALIGN, "resize_normalize_u8: out and xtab must be 16-byte aligned");
+    MUMPY_REQUIRE(std3[0] != 0.f && std3[1] != 0.f && std3[2] != 0.f, MUMPY_EINVAL, "resize_normalize_u8: zero std");
+    if (nframes == 0) return 0;
+    const int64_t total = nframes * 3 * (int64_t)H * (W / 4);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(resize_normalize_u8_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), frames, out, ytab, xtab,
+                       nframes, Hs, Ws, H, W, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+    MUMPY_CHECK_LAUNCH("resize_normalize_u8");
+    return 0;
+}
+
 extern "C" int mumpy_normalize_u8_fwd(const uint8_t* frames, float* out, int64_t nframes, int H, int W, const float* mean3,
                                       const float* std3, void* stream) {
     MUMPY_REQUIRE(frames && out && mean3 && std3, MUMPY_ENULL, "normalize_u8: null pointer");

@@ -11,10 +11,11 @@ from .distributed import all_reduce_metric, eval_metric_vector
 
 @torch.no_grad()
 def eval_step(encoder, decoder, x, gt_mask=None, thr=0.5):
-    """x: (B,T,3,224,224) float32 clip, or (B,T,224,224,3) uint8 frames (then ToTensor+Normalize run on device).
+    """x: (B,T,3,224,224) float32 clip, or (B,T,Hs,Ws,3) uint8 frames of any size (then the loader's resize to 224x224 --
+    PIL NEAREST, universaldataset.py:75-79 -- and ToTensor+Normalize run on device in one kernel).
     Returns (mask uint8 (B,1,224,224), logits, metric_vector or None)."""
     if x.dtype == torch.uint8:
-        x = ops.normalize_u8(x)
+        x = ops.normalize_u8(x, size=(224, 224))
     fx, vx, dx = encoder(x)
     logits, mask, _ = decoder.predict_mask(fx, vx, dx, thr)
     metric = eval_metric_vector(mask, gt_mask) if gt_mask is not None else None

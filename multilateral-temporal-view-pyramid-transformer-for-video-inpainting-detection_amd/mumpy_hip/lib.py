@@ -38,6 +38,8 @@ SIGNATURES = {
     "mumpy_sigmoid_threshold_fwd": [c_f, c_f, c_l, c_fl, c_f],
     "mumpy_add_fwd": [c_f, c_f, c_f, c_l, c_f],
     "mumpy_normalize_u8_fwd": [c_f, c_f, c_l, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f],
+    "mumpy_resize_nearest_table": [c_i, c_i, ctypes.POINTER(ctypes.c_int32)],
+    "mumpy_resize_normalize_u8_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_float), c_f],
     "mumpy_mask_loss_workspace_bytes": [c_i, c_l],
     "mumpy_mask_loss_fwd_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_fl, c_fl, c_f],
     "mumpy_layernorm_bwd_workspace_bytes": [c_l, c_i],

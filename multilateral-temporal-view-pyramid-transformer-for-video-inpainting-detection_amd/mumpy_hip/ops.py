@@ -364,8 +364,27 @@ def sigmoid_threshold(logits, thr=0.5):
 EVAL_MEAN, EVAL_STD = (0.4776, 0.479, 0.4465), (0.230, 0.2085, 0.2324)      # test.py:23-24
 
 
-def normalize_u8(frames, mean=EVAL_MEAN, std=EVAL_STD):
-    """frames (..., H, W, 3) uint8 on the GPU -> (..., 3, H, W) float32, ToTensor + Normalize (test.py:22-25)."""
+_NEAREST_TABLES = {}
+
+
+def _nearest_table(src: int, dst: int, device) -> torch.Tensor:
+    """Pillow's NEAREST source indices for a src -> dst resize (built by the library's host helper, cached on the device)."""
+    import ctypes
+    key = (src, dst, str(device))
+    t = _NEAREST_TABLES.get(key)
+    if t is None:
+        host = (ctypes.c_int32 * dst)()
+        rc = _lib().mumpy_resize_nearest_table(src, dst, host)
+        if rc:
+            raise RuntimeError(f"mumpy_resize_nearest_table failed ({rc}): {_lib().mumpy_last_error().decode()}")
+        t = _NEAREST_TABLES[key] = torch.tensor(list(host), dtype=torch.int32, device=device)
+    return t
+
+
+def normalize_u8(frames, mean=EVAL_MEAN, std=EVAL_STD, size=None):
+    """frames (..., H, W, 3) uint8 on the GPU -> (..., 3, H, W) float32, ToTensor + Normalize (test.py:22-25).
+    size=(H_out, W_out): the loader's `img.resize(inputRes)` (universaldataset.py:75-79, PIL NEAREST as in the pinned
+    pillow==4.0.0) runs in the same kernel, e.g. size=(224, 224) for 432x240 footage."""
     import ctypes
     if not frames.is_cuda or frames.dtype != torch.uint8 or frames.shape[-1] != 3:
         raise RuntimeError("mumpy_hip: normalize_u8 needs a uint8 GPU tensor (..., H, W, 3) (there is no CPU path)")
@@ -374,6 +393,14 @@ def normalize_u8(frames, mean=EVAL_MEAN, std=EVAL_STD):
     n = 1
     for d in lead:
         n *= d
+    if size is not None and tuple(size) != (h, w):
+        ho, wo = size
+        out = torch.empty(*lead, 3, ho, wo, device=frames.device, dtype=torch.float32)
+        m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
+        ytab, xtab = _nearest_table(h, ho, frames.device), _nearest_table(w, wo, frames.device)
+        _call("mumpy_resize_normalize_u8_fwd", _p(frames), _p(out), _p(ytab), _p(xtab), n, h, w, ho, wo, m3, s3, _stream(),
+              work=float(5 * out.numel()))
+        return out
     out = torch.empty(*lead, 3, h, w, device=frames.device, dtype=torch.float32)
     m3, s3 = (ctypes.c_float * 3)(*mean), (ctypes.c_float * 3)(*std)
     _call("mumpy_normalize_u8_fwd", _p(frames), _p(out), n, h, w, m3, s3, _stream(), work=float(frames.numel() + 4 * out.numel()))

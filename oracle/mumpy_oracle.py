@@ -439,6 +439,29 @@ def baseline_decoder_forward(sd: SD, x: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------
 # eval-harness tail (test.py:100-111) and F1/IoU (measure.py:57-62, 86-89)
 # ----------------------------------------------------------------------------------------------
+def stage_frames(frames: torch.Tensor, size=None, mean=(0.4776, 0.479, 0.4465), std=(0.230, 0.2085, 0.2324)) -> torch.Tensor:
+    """Input staging of the loader + eval transforms (universaldataset.py:75-79, test.py:22-25): frames (..., Hs, Ws, 3) uint8
+    -> optional PIL `img.resize(inputRes)` with the default filter of the pinned pillow==4.0.0 (NEAREST: Pillow's Geometry.c
+    ImagingScaleAffine walks xo = 0.5 a, xin = int(xo), xo += a with a = src / dst in double -- the accumulated value
+    decides exact ties, so the walk is restated as a sequential float64 cumulative sum) -> ToTensor
+    (/255) -> Normalize(mean, std) -> (..., 3, H, W) float32.  Pinned against PIL's own NEAREST resize in
+    tests/test_oracle_golden.py::test_stage_frames_matches_pil_nearest."""
+    hs, ws = frames.shape[-3], frames.shape[-2]
+    if size is not None and tuple(size) != (hs, ws):
+        h, w = size
+        def walk(src, dst):
+            a = src / dst
+            steps = torch.full((dst,), a, dtype=torch.float64)
+            steps[0] = a * 0.5
+            return torch.clamp(torch.cumsum(steps, 0).floor().long(), max=src - 1)      # cumsum adds left to right
+        yi, xi = walk(hs, h), walk(ws, w)
+        frames = frames.index_select(-3, yi).index_select(-2, xi)
+    x = frames.movedim(-1, -3).float() / 255.0
+    m = torch.tensor(mean, dtype=torch.float32).view(3, 1, 1)
+    sd = torch.tensor(std, dtype=torch.float32).view(3, 1, 1)
+    return (x - m) / sd
+
+
 def mask_from_logits(logits: torch.Tensor) -> torch.Tensor:
     return (torch.sigmoid(logits) > 0.5).to(torch.uint8)
 

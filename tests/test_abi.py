@@ -83,3 +83,18 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setenv("MUMPY_HIP_LIB", str(tmp_path / "nope.so"))
     with pytest.raises(RuntimeError, match="no CPU/torch fallback"):
         L.load_library()
+
+
+@pytest.mark.parametrize("src,dst", [(432, 224), (240, 224), (1920, 224), (1080, 224), (224, 224), (37, 224), (854, 448)])
+def test_resize_nearest_table_is_pillows(src, dst):
+    """The host helper behind mumpy_resize_normalize_u8_fwd reproduces PIL's NEAREST source indices (incl. the exact ties
+    that Pillow's double accumulator decides, e.g. 1920 -> 224): checked against PIL resizing an index ramp."""
+    import numpy as np
+    from PIL import Image
+    from mumpy_hip.lib import load_library
+    lib = load_library()
+    tab = (ctypes.c_int32 * dst)()
+    assert lib.mumpy_resize_nearest_table(src, dst, tab) == 0
+    ramp = np.arange(src, dtype=np.int32).reshape(1, src)                     # mode "I": pixel value = source column
+    pil = np.array(Image.fromarray(ramp, mode="I").resize((dst, 1), Image.NEAREST)).reshape(-1)
+    assert list(tab) == pil.tolist()

@@ -317,6 +317,44 @@ def test_normalize_u8_input_staging():
     assert rel_err(out, ref) < 1e-6
 
 
+@pytest.mark.parametrize("hs,ws", [(240, 432), (480, 854), (100, 37), (224, 224)])
+def test_resize_normalize_u8_input_staging(hs, ws):
+    """Config 4's 432x240 footage enters the model as in the reference: PIL NEAREST resize to 224x224 (universaldataset.py:75-79
+    with the pinned pillow's default filter) + ToTensor + Normalize, one kernel; bit exact against the oracle, which is pinned
+    against PIL itself (test_stage_frames_matches_pil_nearest)."""
+    g = torch.Generator().manual_seed(hs + ws)
+    frames = torch.randint(0, 256, (2, 3, hs, ws, 3), generator=g, dtype=torch.uint8)
+    out = ops.normalize_u8(frames.to(DEV), size=(224, 224)).cpu()
+    ref = O.stage_frames(frames, size=(224, 224))
+    assert out.shape == (2, 3, 3, 224, 224)
+    assert rel_err(out, ref) < 1e-6
+    sel = ((out - ref).abs() > 1e-5).sum()
+    assert int(sel) == 0                                   # every pixel picked the same source pixel
+
+
+def test_config4_dvi_footage_t9_eval_step():
+    """Config 4 as the reference itself would run it: 432x240 (16:9 DVI) uint8 frames, T = 9 -> the loader's resize to 224x224
+    (PIL NEAREST) + ToTensor + Normalize on device -> three-view model with tubelets (9,8,1) -> thresholded mask.
+    Checked against the oracle fed by its own PIL-pinned staging (the 432x240 geometry itself is outside the
+    reference's envelope; the reference resizes such footage, universaldataset.py:75-79, test.py:32)."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    from mumpy_hip.evaluate import eval_step
+    enc = _load_filled(Encoder(num_frames=9), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 9]), DEV)
+    g = torch.Generator().manual_seed(432240)
+    base = torch.randint(0, 256, (1, 9, 30, 54, 3), generator=g, dtype=torch.uint8)       # blocky frames: 8x8 px cells
+    frames = base.repeat_interleave(8, 2).repeat_interleave(8, 3)
+    assert frames.shape == (1, 9, 240, 432, 3)
+    mask, logits, _ = eval_step(enc, dec, frames.to(DEV))
+    x = O.stage_frames(frames, size=(224, 224))
+    with torch.no_grad():
+        ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)[0]
+    assert rel_err(logits.cpu(), ref) < TOL
+    agree = (mask.cpu() == O.mask_from_logits(ref)).float().mean()
+    assert float(agree) > 0.999
+
+
 def test_sigmoid_threshold():
     z = seeded_randn(4, 2, 1, 224, 224)
     z[0, 0, 0, :4] = torch.tensor([0.0, 1e-7, -1e-7, 30.0])

@@ -271,3 +271,18 @@ def test_baseline_decoder(full_golden):
         z = O.baseline_decoder_forward(sd, torch.from_numpy(full_golden["base_b1t3/y"]))
     assert z.shape == (1, 1, 224, 224)
     assert rel_err(z, full_golden["base_b1t3/logits"]) < FULL_TOL
+
+
+@pytest.mark.parametrize("hs,ws", [(240, 432), (480, 854), (224, 224), (1080, 1920), (100, 37)])
+def test_stage_frames_matches_pil_nearest(hs, ws):
+    """SURVEY 8f-4 / config 4's 432x240 footage: the oracle's resize rule is PIL's NEAREST (the default filter of the pinned
+    pillow==4.0.0 in `img.resize(self.inputRes)`, universaldataset.py:75-79), checked against PIL itself, bit exact."""
+    from PIL import Image
+    g = torch.Generator().manual_seed(hs * 7 + ws)
+    frame = torch.randint(0, 256, (hs, ws, 3), generator=g, dtype=torch.uint8)
+    pil = torch.from_numpy(np.array(Image.fromarray(frame.numpy()).resize((224, 224), Image.NEAREST)))     # PIL takes (W, H)
+    ref = (pil.permute(2, 0, 1).float() / 255.0 - torch.tensor([0.4776, 0.479, 0.4465]).view(3, 1, 1)) / torch.tensor(
+        [0.230, 0.2085, 0.2324]).view(3, 1, 1)
+    out = O.stage_frames(frame, size=(224, 224))
+    assert out.shape == (3, 224, 224)
+    assert torch.equal(out, ref)
