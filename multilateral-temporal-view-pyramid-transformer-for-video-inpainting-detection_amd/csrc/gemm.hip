@@ -388,7 +388,11 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
 // one basic block so the scheduler interleaves split VALU / LDS / loads with the MFMA stream): 112 us; (ii) removing the
 // W-side split arithmetic altogether (an upper bound for pre-split weights): 108 us.  Two different structures and half
 // the VALU landing on one rate points at what they share -- the MFMA count at the clock the chip holds under bf16-MFMA
-// load plus the LDS bytes per MFMA (three planes per operand).
+// load plus the LDS bytes per MFMA (three planes per operand).  Confirmed by (iii): with the split VALU kept but the piece
+// stores to LDS dropped (wrong results, timing only) the same launch takes 81 us instead of 114 on the box of that run --
+// the VGPR->LDS store path (6 bytes per staged element at ~80 B/clk/CU) is the largest single cost after the MFMAs.
+// Splitting AFTER the LDS (raw fp32 tiles by LDS-DMA, split per wave) would remove it but doubles the split VALU
+// (each tile row is consumed by two waves), which then saturates vector issue; pre-split weights by DMA remove half.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
