@@ -137,7 +137,7 @@ def north_star_kernels(batch, frames, dev):
     t = timed(lambda: ops.deform_sample(x2, pos, batch, hs, w, c2, batch * 64))
     nbytes = 4.0 * (2 * nwin * 49 * c2 + nwin * 3 * 49 * 2)
     ach = nbytes / t / 1e9
-    out["deform_sample"] = {"kernel": "deform_sample_kernel<96>", "launch": f"{nwin} kv windows x 49 points x {c2} ch",
+    out["deform_sample"] = {"kernel": "deform_sample_lds_kernel<96>", "launch": f"{nwin} kv windows x 49 points x {c2} ch",
                             "bound": "hbm", "bytes_per_launch": int(nbytes), "avg_us": round(t * 1e6, 2), "achieved": round(ach, 1),
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4)}
     return out

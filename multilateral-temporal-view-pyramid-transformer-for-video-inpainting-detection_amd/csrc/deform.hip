@@ -2,6 +2,7 @@
 // (mTVE:138, 280-286): offset network, bilinear sampling, and the "scrambled" combine.
 // The attention + r-tuple aggregation lives in window_attention.hip (win_attn_cross_kernel); q/k/v/out projections
 // and `pre` are mumpy_linear_fwd.
+#include <stdlib.h>
 #include "common.h"
 using namespace mumpy;
 
@@ -143,6 +144,53 @@ __global__ __launch_bounds__(256) void deform_sample_kernel(const float* __restr
     }
 }
 
+// LDS-staged form (the one the entry point launches): one block per (kv window, 96-channel slab).  The slab of the window
+// tile, 49 tokens x 96 channels = 18.4 KB, is read ONCE with coalesced 16-byte loads (7 row segments of 7 x 384 B) into LDS and
+// all four corner reads of every point come from there, so HBM sees exactly the algorithmic bytes: the direct form above
+// fetched ~1.5x the tile (PMC FETCH_SIZE: corner rows touched a second time after leaving L2) -- profiles/r01_pmc_traffic.md.
+// Eight blocks per CU fit (147 KB of LDS), lanes run over channels so a point's corner read is one contiguous 384-B LDS row.
+template <int C>
+__global__ __launch_bounds__(256) void deform_sample_lds_kernel(const float* __restrict__ x2, const float* __restrict__ pos,
+                                                                float* __restrict__ out, int Hs2, int W, int nWx, int nW2,
+                                                                int nq) {
+    constexpr int SL = 96, S4 = SL / 4, CG = C / 3;
+    __shared__ __attribute__((aligned(16))) float tile[WT * SL];
+    const int b2 = blockIdx.x, slab = blockIdx.y;
+    const int b = b2 / nW2, n = b2 - b * nW2;
+    const int wy = n / nWx, wx = n - wy * nWx;
+    const float* base = x2 + ((int64_t)b * Hs2 * W + (int64_t)wy * WS * W + wx * WS) * C + slab * SL;
+    for (int idx = threadIdx.x; idx < WT * S4; idx += 256) {
+        const int tok = idx / S4, j = idx - tok * S4;
+        const int ty = tok / WS, tx = tok - ty * WS;
+        *reinterpret_cast<f32x4*>(&tile[tok * SL + 4 * j]) = *reinterpret_cast<const f32x4*>(base + (ty * W + tx) * C + 4 * j);
+    }
+    __syncthreads();
+    const float* pw = pos + (int64_t)(b2 % nq) * 3 * WT * 2;
+    float* ob = out + (int64_t)b2 * WT * C + slab * SL;
+    for (int idx = threadIdx.x; idx < WT * S4; idx += 256) {
+        const int p = idx / S4, c4 = idx - p * S4;
+        const int g = (slab * SL + 4 * c4) / CG;
+        const float gy = pw[(g * WT + p) * 2], gx = pw[(g * WT + p) * 2 + 1];
+        const float iy = ((gy + 1.0f) * 0.5f) * 6.0f;        // grid_sample, align_corners=True: pixel = (g + 1) / 2 * (size - 1)
+        const float ix = ((gx + 1.0f) * 0.5f) * 6.0f;
+        const float y0f = floorf(iy), x0f = floorf(ix);
+        const int y0 = (int)y0f, x0 = (int)x0f;
+        const float wnw = (x0f + 1.0f - ix) * (y0f + 1.0f - iy);
+        const float wne = (ix - x0f) * (y0f + 1.0f - iy);
+        const float wsw = (x0f + 1.0f - ix) * (iy - y0f);
+        const float wse = (ix - x0f) * (iy - y0f);
+        auto corner = [&](int yy, int xx) -> f32x4 {
+            if (yy < 0 || yy >= WS || xx < 0 || xx >= WS) return f32x4{0, 0, 0, 0};   // zeros padding
+            return *reinterpret_cast<const f32x4*>(&tile[(yy * WS + xx) * SL + 4 * c4]);
+        };
+        f32x4 r = corner(y0, x0) * wnw;                       // same order of operations as the direct form: bitwise equal
+        r += corner(y0, x0 + 1) * wne;
+        r += corner(y0 + 1, x0) * wsw;
+        r += corner(y0 + 1, x0 + 1) * wse;
+        *reinterpret_cast<f32x4*>(ob + p * C + 4 * c4) = r;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // combine: out[b, n*49+p, c] = x1[b, n*49+p, c] + x1[b, raster(n,p), c] + Yt[bw]^T flat[p*C + c]
 // One block per (window, 32-channel slab of Yt): the slab [49][32] is transposed through LDS (row stride 33) and
@@ -217,9 +265,14 @@ extern "C" int mumpy_deform_sample_fwd(const float* x2, const float* pos, float*
     const int nWx = W / WS, nW2 = (Hs2 / WS) * nWx;
     const int64_t nwin = (int64_t)B * nW2;
     MUMPY_REQUIRE(nwin < (1ll << 31), MUMPY_ERANGE, "deform_sample: too many windows");
+    static const bool direct = getenv("MUMPY_SAMPLE_DIRECT") && atoi(getenv("MUMPY_SAMPLE_DIRECT")) != 0;   // A/B hook
 #define MUMPY_SAMPLE(C_)                                                                                             \
-    hipLaunchKernelGGL(deform_sample_kernel<C_>, dim3((unsigned)nwin), dim3(256), 0, as_stream(stream), x2, pos, out, Hs2, \
-                       W, nWx, nW2, nq)
+    if (direct)                                                                                                      \
+        hipLaunchKernelGGL(deform_sample_kernel<C_>, dim3((unsigned)nwin), dim3(256), 0, as_stream(stream), x2, pos, out,  \
+                           Hs2, W, nWx, nW2, nq);                                                                    \
+    else                                                                                                             \
+        hipLaunchKernelGGL(deform_sample_lds_kernel<C_>, dim3((unsigned)nwin, C_ / 96), dim3(256), 0, as_stream(stream), x2, \
+                           pos, out, Hs2, W, nWx, nW2, nq)
     switch (C) {
         case 96: MUMPY_SAMPLE(96); break;
         case 192: MUMPY_SAMPLE(192); break;
