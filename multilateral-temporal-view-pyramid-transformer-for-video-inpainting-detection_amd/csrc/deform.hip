@@ -43,16 +43,22 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
     __syncthreads();
     for (int p = tid / Cg; p < WT; p += 256 / Cg) {
         const int py = p / WS, px = p - py * WS;
+        // branch-free taps: out-of-window taps read the centre pixel and contribute fmaf(0, w, acc) == acc, so the 25 LDS
+        // reads of a pixel are independent and issue back to back (the `continue` form serialised them behind branches:
+        // 66 us for the 24 blocks of the widest call, all of it LDS latency)
         float acc = breg;
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
             const int yy = py + dy - 2;
-            if (yy < 0 || yy >= WS) continue;
+            const bool vy = (unsigned)yy < (unsigned)WS;
+            const int yc = vy ? yy : py;
 #pragma unroll
             for (int dx = 0; dx < 5; ++dx) {
                 const int xx = px + dx - 2;
-                if (xx < 0 || xx >= WS) continue;
-                acc = fmaf(tile[(yy * WS + xx) * Cg + cc], wreg[dy * 5 + dx], acc);
+                const bool ok = vy && (unsigned)xx < (unsigned)WS;
+                const int xc = ok ? xx : px;
+                const float t = tile[(yc * WS + xc) * Cg + cc];
+                acc = fmaf(ok ? t : 0.f, wreg[dy * 5 + dx], acc);
             }
         }
         conv[p * Cg + cc] = acc;
