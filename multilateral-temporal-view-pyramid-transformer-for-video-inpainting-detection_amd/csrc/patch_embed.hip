@@ -26,23 +26,45 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     const int Hp = H >> 2, Wp = W >> 2;
     const int64_t m0 = (int64_t)blockIdx.x * TM;
     const int kq = K >> 2;          // float4 chunks per patch: (cin, dt, dy)
-    for (int idx = tid; idx < TM * kq; idx += 256) {
-        const int ml = idx % TM, q = idx / TM;
+    // a thread stages ONE token (ml = tid % 64: the stride 256 of the loop is a multiple of 64), so the token's image
+    // coordinates are decoded once -- the 64-bit divisions were paid per staged float4 before (15x per thread at t = 5)
+    {
+        const int ml = tid & (TM - 1);
         const int64_t m = m0 + ml;
-        f32x4 v = {0, 0, 0, 0};
-        if (m < Mtot) {
+        const bool live = m < Mtot;
+        const float* src = x;
+        if (live) {
             const int hx = (int)(m % Wp);
             int64_t r = m / Wp;
             const int hy = (int)(r % Hp);
             r /= Hp;
             const int to = (int)(r % t_out);
             const int64_t b = r / t_out;
-            const int dy = q & 3, dt = (q >> 2) % t, cin = (q >> 2) / t;
-            const int64_t off = ((((b * T + (to * t + dt)) * 3 + cin) * H + (4 * hy + dy)) * (int64_t)W) + 4 * hx;
-            v = *reinterpret_cast<const f32x4*>(x + off);
+            src = x + (((b * T + to * t) * 3) * H + 4 * hy) * (int64_t)W + 4 * hx;      // (frame to*t, cin 0, row 4 hy)
         }
-        float* dst = As + ml * lda + 4 * q;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        const int64_t plane = (int64_t)H * W;                      // one (frame, channel) image
+        float* drow = As + ml * lda;
+        // loads in batches of up to 5 (all issued before the first LDS write: one memory latency per batch, not per load;
+        // padding tokens of the last block re-read token 0's patch and are never stored)
+        for (int q0 = tid >> 6; q0 < kq; q0 += 20) {                // q = (cin*t + dt)*4 + dy, this thread's q step is 4
+            f32x4 v[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int q = q0 + 4 * j;
+                const int qq = q < kq ? q : q0;
+                const int dy = qq & 3, ct = qq >> 2;
+                const int dt = ct % t, cin = ct / t;
+                v[j] = *reinterpret_cast<const f32x4*>(src + (dt * 3 + cin) * plane + dy * W);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int q = q0 + 4 * j;
+                if (q < kq) {
+                    float* dst = drow + 4 * q;
+                    dst[0] = v[j].x; dst[1] = v[j].y; dst[2] = v[j].z; dst[3] = v[j].w;
+                }
+            }
+        }
     }
     __syncthreads();
     const int ntile = C >> 5;       // 3 or 4 column tiles; wave w owns tile w

@@ -237,16 +237,18 @@ class CrossThreeViewTokenize(nn.Module):
             setattr(self, f"norm{v + 1}", nn.LayerNorm(view_configs[v]["hidden_size"][0]))
         self._wt = [Derived(), Derived(), Derived()]
 
+    def _view(self, v, x):
+        proj, norm = getattr(self, f"project{v + 1}"), getattr(self, f"norm{v + 1}")
+        w = proj.weight
+        if tuple(w.shape[3:]) != (4, 4):
+            raise NotImplementedError("tokenizer kernel is built for 4x4 spatial patches")
+        wt = self._wt[v].get((w,), lambda: w.reshape(w.shape[0], -1).t().contiguous())
+        return ops.patch_embed(x, wt, proj.bias, norm.weight, norm.bias, w.shape[2], norm.eps)
+
     def forward(self, x):
-        outs = []
-        for v in range(3):
-            proj, norm = getattr(self, f"project{v + 1}"), getattr(self, f"norm{v + 1}")
-            w = proj.weight
-            if tuple(w.shape[3:]) != (4, 4):
-                raise NotImplementedError("tokenizer kernel is built for 4x4 spatial patches")
-            wt = self._wt[v].get((w,), lambda: w.reshape(w.shape[0], -1).t().contiguous())
-            outs.append(ops.patch_embed(x, wt, proj.bias, norm.weight, norm.bias, w.shape[2], norm.eps))
-        return outs
+        # the three tokenizers read the same clip and are independent: views 1/2 (392 blocks each, latency-bound) run
+        # on side streams beside view 3's launch instead of in front of it
+        return run_parallel([lambda: self._view(0, x), lambda: self._view(1, x), lambda: self._view(2, x)], [(x,), (x,), (x,)])
 
 
 class CreateGlobalBlocks(nn.Module):
