@@ -39,6 +39,28 @@ def test_linear_random_shapes(case):
     assert rel_err(y.cpu().double(), ref) < 5e-6
 
 
+@pytest.mark.parametrize("case", list(_linear_cases(24, 4048)), ids=lambda c: f"{c[1]}x{c[2]}x{c[3]}")
+def test_linear_bf16x3_random_shapes(case):
+    """The same sweep in split-precision mode (both tiles, every K-split plan, ragged M, epilogues): fp32-level error."""
+    from mumpy_hip import ops
+    i, m, n, k, gelu, res, bias = case
+    x, w = seeded_randn(1100 + i, m, k), seeded_randn(2100 + i, n, k) / k ** 0.5
+    b = seeded_randn(3100 + i, n) if bias else None
+    r = seeded_randn(4100 + i, m, n) if res else None
+    ref = F.linear(x.double(), w.double(), None if b is None else b.double())
+    if gelu:
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    ops.set_matrix_math("bf16x3")
+    try:
+        y = ops.linear(x.cuda(), w.cuda(), None if b is None else b.cuda(), act=ops.ACT_GELU if gelu else ops.ACT_NONE,
+                       residual=None if r is None else r.cuda())
+    finally:
+        ops.set_matrix_math("fp32")
+    assert rel_err(y.cpu().double(), ref) < 5e-6
+
+
 def _wa_cases(n, seed):
     rng = random.Random(seed)
     for i in range(n):
