@@ -392,7 +392,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
 // stores to LDS dropped (wrong results, timing only) the same launch takes 81 us instead of 114 on the box of that run --
 // the VGPR->LDS store path (6 bytes per staged element at ~80 B/clk/CU) is the largest single cost after the MFMAs.
 // Splitting AFTER the LDS (raw fp32 tiles by LDS-DMA, split per wave) would remove it but doubles the split VALU
-// (each tile row is consumed by two waves), which then saturates vector issue; pre-split weights by DMA remove half.
+// (each tile row is consumed by two waves), which then saturates vector issue.  Dropping only the W-side piece stores
+// (what pre-split weights fetched by LDS-DMA would remove) gives 110 -> 107.6 us: the cost is not store throughput but the
+// split -> store -> barrier -> fragment-read chain of a chunk, which half the stores leave in place.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
