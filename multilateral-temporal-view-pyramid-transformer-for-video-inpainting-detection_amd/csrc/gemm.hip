@@ -395,6 +395,16 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
 // (each tile row is consumed by two waves), which then saturates vector issue.  Dropping only the W-side piece stores
 // (what pre-split weights fetched by LDS-DMA would remove) gives 110 -> 107.6 us: the cost is not store throughput but the
 // split -> store -> barrier -> fragment-read chain of a chunk, which half the stores leave in place.
+// (v) a WAVE-SPECIALISED form was built and measured (bit-correct on the whole bf16x3 test set, not kept): 8 waves per 128x128
+// tile, one block per CU, two LDS buffers of three planes (120 KB); waves 0-3 only read fragments and issue MFMAs, waves
+// 4-7 only load, split and store the other buffer, raw s_barrier hand-over per chunk (lgkmcnt-only wait, so the split
+// waves' prefetch survives the barrier).  M=7840 N=512 K=2048 (248 tiles, one round): 102 us vs 117 us for the form kept here
+// -- but the K=512 shapes lose (135 vs 115 us: prologue and epilogue are exposed at one block per CU; a persistent tile loop
+// would be the next step).  Its ablation locates the costs: matrix waves alone, no split work and no fragment reads, 68 us
+// (= 48 MFMAs x 32 cycles per chunk at the ~1.64 GHz the chip holds under this load: the floor); + fragment reads 81.5 us;
+// + split work on the partner wave of each SIMD 107 us.  So once the chain is off the critical path the limiter is vector
+// ISSUE: per MFMA slot the SIMD must also issue ~4 split/LDS instructions of the partner wave.  Moving the hand-over
+// barrier to mid-chunk (fragment reads fully under MFMAs) and v_pk_add_f32 for the remainders both measured slower.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
