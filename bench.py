@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="clips per GPU (micro-batch)")
     ap.add_argument("--frames", type=int, default=5)
-    ap.add_argument("--math", choices=["fp32", "bf16", "bf16x3"], default="fp32",
+    ap.add_argument("--math", choices=["fp32", "bf16", "bf16x3", "bf16x2"], default="fp32",
                     help="matrix arithmetic of the GEMMs/convolutions: fp32 on the fp32 MFMA (headline, default), bf16x3 = fp32 "
                          "products from three bf16 pieces per operand on the bf16 MFMA (fp32-level accuracy), bf16 = bf16 "
                          "operands + fp32 accumulate")
@@ -282,6 +282,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (matrix products from 3 bf16 pieces per operand on the bf16 MFMA, f32 accumulate)",
+                      "bf16x2": "matrix operands as 2 bf16 pieces (16 mantissa bits, TF32-class), f32 accumulate and storage",
                       "bf16": "bf16 matrix operands, f32 accumulate and storage"}[args.math], "data": "synthetic",
             "config": {"workload": f"full Mumpy forward (3 temporal views, pyramid decoder), B={args.batch} clips/GPU, "
                                    f"T={args.frames}, 224x224, fp32, tubelets ({args.frames},{args.frames - 1},1)",
@@ -297,31 +298,34 @@ def main():
             "eval_metric": {"f1": float(metric[0] / metric[2]), "iou": float(metric[1] / metric[2]), "clips": int(metric[2])},
         }
         if args.math == "fp32" and world == 1 and not args.no_alt:
-            try:
-                # the same workload with the GEMMs / convolutions in split-precision mode (fp32-level accuracy, tests:
-                # test_linear_bf16x3_math, test_full_model_bf16x3_math_t5): reported beside the headline, never as `value`
-                log("alt: bf16x3 matrix math")
-                ops.set_matrix_math("bf16x3")
-                with torch.no_grad():
-                    fused_forward(enc, dec, x, with_mask=True)
-                fwd3 = None if args.no_graph else GraphedForward(enc, dec, x, with_mask=True)
-                run3 = (lambda: fused_forward(enc, dec, x, with_mask=True)[1]) if fwd3 is None else (lambda: fwd3(x)[1])
-                for _ in range(2):
-                    run3()
-                torch.cuda.synchronize()
-                t3 = time.perf_counter()
-                for _ in range(args.steps):
-                    mask3 = run3()
-                torch.cuda.synchronize()
-                dt3 = time.perf_counter() - t3
-                ops.set_matrix_math("fp32")
-                out["alt_bf16x3"] = {"math": "fp32 products as 6 bf16 piece products (3 pieces per operand), f32 accumulate",
-                                     "value": round(args.batch * args.steps / dt3, 3), "unit": "clips/s",
-                                     "ms_per_step": round(1e3 * dt3 / args.steps, 3),
-                                     "mask_pixels_differing_from_fp32_path": int((mask3 != mask).sum())}
-            except Exception as e:              # the extra measurement must never cost the headline line
-                ops.set_matrix_math("fp32")
-                out["alt_bf16x3"] = {"error": repr(e)[:200]}
+            # the same workload with the GEMMs / convolutions in the split-precision modes: bf16x3 (fp32-level accuracy, tests:
+            # test_linear_bf16x3_math, test_full_model_bf16x3_math_t5) and bf16x2 (16-bit-mantissa operands, TF32-class:
+            # test_linear_bf16x2_math) -- reported beside the headline, never as `value`
+            for mode, what in (("bf16x3", "fp32 products as 6 bf16 piece products (3 pieces per operand), f32 accumulate"),
+                               ("bf16x2", "3 bf16 piece products (2 pieces = 16 mantissa bits per operand), f32 accumulate")):
+                try:
+                    log(f"alt: {mode} matrix math")
+                    ops.set_matrix_math(mode)
+                    with torch.no_grad():
+                        fused_forward(enc, dec, x, with_mask=True)
+                    fwd3 = None if args.no_graph else GraphedForward(enc, dec, x, with_mask=True)
+                    run3 = (lambda: fused_forward(enc, dec, x, with_mask=True)[1]) if fwd3 is None else (lambda: fwd3(x)[1])
+                    for _ in range(2):
+                        run3()
+                    torch.cuda.synchronize()
+                    t3 = time.perf_counter()
+                    for _ in range(args.steps):
+                        mask3 = run3()
+                    torch.cuda.synchronize()
+                    dt3 = time.perf_counter() - t3
+                    out["alt_" + mode] = {"math": what, "value": round(args.batch * args.steps / dt3, 3), "unit": "clips/s",
+                                          "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                                          "mask_pixels_differing_from_fp32_path": int((mask3 != mask).sum())}
+                    del fwd3
+                except Exception as e:          # the extra measurements must never cost the headline line
+                    out["alt_" + mode] = {"error": repr(e)[:200]}
+                finally:
+                    ops.set_matrix_math("fp32")
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores)")
             try:

@@ -45,6 +45,10 @@ extern "C" {
  * accumulated in fp32; the dropped terms are <= 2^-24 |a||b|, one fp32 rounding.  fp32-level accuracy at 6/16 of the
  * fp32 MFMA time.  Operands outside bf16's exponent handling (inf, NaN, |v| < 2^-110) are not split faithfully. */
 #define MUMPY_MATH_BF16X3 0x200
+/* Likewise with TWO pieces per operand (16 mantissa bits kept) and the three piece products a0b0 + a0b1 + a1b0: operand
+ * precision 2^-17, i.e. TF32-class and better (TF32 keeps 11 bits; gfx950 has no xf32 MFMA) at 3/16 of the fp32 MFMA time.
+ * A reduced-precision mode like MUMPY_MATH_BF16 (error ~1e-5 relative instead of ~1e-2), never the default. */
+#define MUMPY_MATH_BF16X2 0x400
 
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);

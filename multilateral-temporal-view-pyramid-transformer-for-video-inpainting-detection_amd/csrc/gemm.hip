@@ -520,8 +520,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     // piece products, smallest weight first: (a2 b0) (a0 b2) (a1 b1) | (a1 b0) (a0 b1) | (a0 b0)
-    constexpr int NPROD = (NP == 3) ? 6 : 1;
-    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    // NP == 2 (MUMPY_MATH_BF16X2): two pieces per operand = 16 mantissa bits, products (a1 b0) (a0 b1) (a0 b0)
+    constexpr int NPROD = (NP == 3) ? 6 : (NP == 2) ? 3 : 1;
+    constexpr int PA[6] = {NP == 3 ? 2 : 1, 0, NP == 3 ? 1 : 0, 1, 0, 0}, PB[6] = {0, NP == 3 ? 2 : 1, NP == 3 ? 1 : 0, 0, 1, 0};
     const int nk = K / ksplit / BK;
     bf16x8 af[TM][2][NP], bf[TN][2][NP];
     auto fread = [&](int buf) {
@@ -549,8 +550,8 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st][NP == 3 ? PA[q] : 0],
-                                                                            bf[j][st][NP == 3 ? PB[q] : 0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][st][NP > 1 ? PA[q] : 0],
+                                                                            bf[j][st][NP > 1 ? PB[q] : 0], acc[i][j], 0, 0, 0);
     };
     const int klast = kbeg + (nk - 1) * BK;
     if (NBUF == 2) {
@@ -694,7 +695,8 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     if (rpb <= 0) { rpb = M; bstride = 0; }
     const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
     const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
-    const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0;
+    const bool math_x2 = (act & MUMPY_MATH_BF16X2) != 0;
+    const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0 || math_x2;      // the two-piece mode shares the three-piece planner
     act &= 0xff;
     Plan p = make_plan(M, N, K, ws != nullptr, math_x3);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
@@ -716,11 +718,21 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
 #define MUMPY_GEMM_X3(BM_, BN_, WM_, WN_, CV_, NB_)                                                                    \
     hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, CV_, 3, NB_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, \
                        bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, cg)
-        if (wide && conv) MUMPY_GEMM_X3(128, 128, 64, 64, true, 1);
+#define MUMPY_GEMM_X2(BM_, BN_, WM_, WN_, CV_, NB_)                                                                    \
+    hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, CV_, 2, NB_>), dim3((unsigned)grid), dim3(256), 0, s, x, W, \
+                       bias, residual, y, M, N, K, act, p.gn, p.ksplit, ws, rpb, bstride, cg)
+        if (math_x2) {
+            if (wide && conv) MUMPY_GEMM_X2(128, 128, 64, 64, true, 1);
+            else if (wide) MUMPY_GEMM_X2(128, 128, 64, 64, false, 1);
+            else if (conv) MUMPY_GEMM_X2(64, 64, 32, 32, true, 2);
+            else MUMPY_GEMM_X2(64, 64, 32, 32, false, 2);
+        }
+        else if (wide && conv) MUMPY_GEMM_X3(128, 128, 64, 64, true, 1);
         else if (wide) MUMPY_GEMM_X3(128, 128, 64, 64, false, 1);
         else if (conv) MUMPY_GEMM_X3(64, 64, 32, 32, true, 2);
         else MUMPY_GEMM_X3(64, 64, 32, 32, false, 2);
 #undef MUMPY_GEMM_X3
+#undef MUMPY_GEMM_X2
     } else if (math_bf16) {
         const bool wide = (p.tile == 0 || p.tile == 3);
 #define MUMPY_GEMM_H(BM_, BN_, WM_, WN_, CV_)                                                                          \
@@ -772,9 +784,9 @@ static int check_linear_args(const float* x, const float* W, const float* residu
     MUMPY_REQUIRE(M >= 0 && N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, MUMPY_EINVAL,
                   "linear: need K %% 32 == 0 and N %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
     MUMPY_REQUIRE((act & 0xff) == MUMPY_ACT_NONE || (act & 0xff) == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear: unknown act %d", act);
-    MUMPY_REQUIRE((act & ~(0xff | MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3)) == 0, MUMPY_EINVAL, "linear: unknown flag bits in act 0x%x", act);
-    MUMPY_REQUIRE((act & (MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3)) != (MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3), MUMPY_EINVAL,
-                  "linear: MUMPY_MATH_BF16 and MUMPY_MATH_BF16X3 are exclusive");
+    constexpr int math_bits = MUMPY_MATH_BF16 | MUMPY_MATH_BF16X3 | MUMPY_MATH_BF16X2;
+    MUMPY_REQUIRE((act & ~(0xff | math_bits)) == 0, MUMPY_EINVAL, "linear: unknown flag bits in act 0x%x", act);
+    MUMPY_REQUIRE(((act & math_bits) & ((act & math_bits) - 1)) == 0, MUMPY_EINVAL, "linear: the MUMPY_MATH_* modes are exclusive");
     return 0;
 }
 

@@ -8,7 +8,7 @@ import torch
 from .lib import load_library
 
 ACT_NONE, ACT_GELU = 0, 1
-MATH_FP32, MATH_BF16, MATH_BF16X3 = 0, 0x100, 0x200
+MATH_FP32, MATH_BF16, MATH_BF16X3, MATH_BF16X2 = 0, 0x100, 0x200, 0x400
 _MATH = MATH_FP32          # OR-ed into the `act` argument of every linear / conv launch
 _WS_BYTES = {}
 
@@ -18,14 +18,15 @@ def set_matrix_math(mode: str) -> None:
     rounded to bf16 while being staged and multiplied on the bf16 MFMA with fp32 accumulation (config 3's arithmetic);
     tensors in memory, LayerNorm / softmax / GroupNorm statistics and all other kernels stay fp32.
     "bf16x3": fp32 products on the bf16 matrix pipe -- each operand is split into three bf16 pieces while staged and the
-    six significant piece products are accumulated in fp32; fp32-level accuracy (see include/mumpy_hip.h)."""
+    six significant piece products are accumulated in fp32; fp32-level accuracy (see include/mumpy_hip.h).
+    "bf16x2": two pieces / three products: 16-bit-mantissa operands (TF32-class and better), a reduced-precision mode."""
     global _MATH
     if mode not in _MODES:
         raise ValueError(f"unknown matrix math mode {mode!r}")
     _MATH = _MODES[mode]
 
 
-_MODES = {"fp32": MATH_FP32, "bf16": MATH_BF16, "bf16x3": MATH_BF16X3}
+_MODES = {"fp32": MATH_FP32, "bf16": MATH_BF16, "bf16x3": MATH_BF16X3, "bf16x2": MATH_BF16X2}
 
 
 def matrix_math() -> str:

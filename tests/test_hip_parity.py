@@ -676,6 +676,45 @@ def test_full_model_bf16x3_math_t5(full_golden, bf16x3_math):
     assert bool((O.mask_from_logits(logits) == O.mask_from_logits(ref)).all()) or err < 1e-5
 
 
+# ------------------------------------------------------------------ two-piece mode: 16-bit-mantissa operands (TF32-class)
+@pytest.mark.parametrize("m,n,k", [(300, 128, 96), (1568, 384, 1536), (7840, 512, 2048), (7840, 2048, 512), (392, 256, 12800)])
+def test_linear_bf16x2_math(m, n, k):
+    """Two bf16 pieces per operand, three piece products: must equal an fp64 product of the operands ROUNDED TO THE TWO-PIECE
+    FORM to fp32 round-off, and stay within the 2^-17 operand precision of the exact product (between bf16 and fp32)."""
+    x, w, b = seeded_randn(m, m, k), seeded_randn(n, n, k) / k ** 0.5, seeded_randn(k, n)
+    ops.set_matrix_math("bf16x2")
+    try:
+        y = ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)).cpu().double()
+    finally:
+        ops.set_matrix_math("fp32")
+
+    def two_piece(t):
+        p0 = t.bfloat16().float()
+        return (p0 + (t - p0).bfloat16().float()).double()
+    ref = F.linear(x.double(), w.double(), b.double())
+    assert rel_err(y.float(), ref.float()) < 2e-5                                      # vs the exact product: ~1e-5 (bf16 mode: ~3e-3)
+    dropped = F.linear(two_piece(x), two_piece(w), b.double())
+    assert rel_err(y.float(), dropped.float()) < 2e-5                                  # only a1*b1 (2^-16 relative) is missing
+
+
+def test_full_model_bf16x2_math_t5(full_golden):
+    """Whole model in two-piece mode against the reference's fp32 golden: inside north_star's 1e-3 bar (bf16 mode: 1.1e-2)."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = golden_input(full_golden, "b1t5/x").to(DEV)
+    ops.set_matrix_math("bf16x2")
+    try:
+        with torch.no_grad():
+            logits = dec(*enc(x))[0].cpu()
+    finally:
+        ops.set_matrix_math("fp32")
+    err = rel_err(logits, torch.tensor(full_golden["b1t5/logits"]))
+    print(f"bf16x2 matrix math: logits rel err {err:.3e}")
+    assert err < 1e-3
+
+
 def test_strict_checkpoint_roundtrip(tmp_path, model_t3):
     """a reference-format checkpoint (encoder_{e}.pt = plain state_dict) loads strictly and reproduces
     the outputs; 'module.'-prefixed (DataParallel) checkpoints are what utils/utils.py:156-176 strips."""
