@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One training step of the full three-view model (Encoder + Decoder) on the HIP kernels: taped forward, mask loss, backward,
-fused AdamW over the cva / encoder / decoder groups (train.py:94-138).  usage: train_full_bench.py [batch] [frames] [--bf16 | --x3] [--graph]
+fused AdamW over the cva / encoder / decoder groups (train.py:94-138).  usage: train_full_bench.py [batch] [frames] [--bf16 | --x3 | --x2] [--graph]
 --x3: split-precision GEMMs / convolutions (fp32 products from three bf16 pieces per operand, fp32-level accuracy).
 --bf16: bf16-operand GEMMs / convolutions (fp32 accumulate, fp32 master weights, fp32 everything else) in forward and backward,
 i.e. config 5's matrix arithmetic; prints the gradient deviation from the fp32 step as well."""
@@ -16,7 +16,7 @@ from mumpy_hip.autograd import decoder_train, encoder_train
 from mumpy_hip.train import build_optimizers
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 BF16 = "--bf16" in sys.argv
-MODE = "bf16x3" if "--x3" in sys.argv else "bf16"
+MODE = "bf16x3" if "--x3" in sys.argv else "bf16x2" if "--x2" in sys.argv else "bf16"
 B = int(args[0]) if args else 2
 T = int(args[1]) if len(args) > 1 else 5
 dev = torch.device("cuda:0")
@@ -33,7 +33,7 @@ def step():
     for o in opts.values():
         o.step(); o.zero_grad()
     return loss3
-if BF16 or MODE == "bf16x3":                # one step's flat encoder gradient in fp32 vs bf16 matrix math, same weights
+if BF16 or MODE != "bf16":                # one step's flat encoder gradient in fp32 vs bf16 matrix math, same weights
     def grads(mode):
         ops.set_matrix_math(mode)
         for o in opts.values():
