@@ -42,6 +42,7 @@
 //     co-scheduled branches, bias + residual no longer fused -- the isolated-kernel advantage does not carry over.
 #include <stdlib.h>
 #include "common.h"
+#include "gemm_ws.h"
 using namespace mumpy;
 
 namespace {
@@ -698,6 +699,26 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     const bool math_x2 = (act & MUMPY_MATH_BF16X2) != 0;
     const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0 || math_x2;      // the two-piece mode shares the three-piece planner
     act &= 0xff;
+    // Large dense fp32 shapes: the persistent wave-specialised kernel (gemm_ws.h).  MUMPY_GEMM_WS=0 disables it, =1 forces
+    // it for every eligible shape (tuning); default: shapes that give every CU at least most of a round of 128x128 tiles.
+    if (!conv && rpb >= M && !math_bf16 && !math_x3 && gemm_ws::eligible(M, N, K)) {
+        static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
+        static int num_cu = 0;
+        if (!num_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+            else num_cu = NUM_CU;
+        }
+        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        const double rounds = (double)tiles / num_cu;
+        const bool balanced = tiles >= (int64_t)(0.85 * num_cu) && (rounds - (int64_t)rounds == 0.0 || rounds - (int64_t)rounds >= 0.8 || rounds >= 6.0);
+        if (ws_mode == 1 || (ws_mode == 2 && balanced && K >= 384)) {
+            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s)) return rc;
+            MUMPY_CHECK_LAUNCH("linear(ws)");
+            return 0;
+        }
+    }
     Plan p = make_plan(M, N, K, ws != nullptr, math_x3);
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;

@@ -27,12 +27,10 @@ namespace gemm_ws {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int STAGE_DW = (BM + BN) * BK;
-constexpr int NSTAGE = 2;
+constexpr int NSTAGE = 3;
 constexpr int E_DW = BM * BN;
-constexpr int PMAX = 4;                   // most epilogue passes per chunk (residual ring: 2 slots x PMAX passes x 4 KB)
 constexpr int E_OFF_DW = NSTAGE * STAGE_DW;
-constexpr int R_OFF_DW = E_OFF_DW + E_DW;
-constexpr int LDS_BYTES = (R_OFF_DW + 2 * PMAX * 1024) * 4;
+constexpr int LDS_BYTES = (E_OFF_DW + E_DW) * 4;
 constexpr int PASSES = BM / 8;              // epilogue passes per tile: 8 rows (4 helper waves x 2 rows) each
 constexpr unsigned NG = 4;                  // N-tiles per group of the tile order
 #ifndef MUMPY_WS_DBG
@@ -157,7 +155,7 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int n_c
     } while (0)
     for (int i = 0; i < n_chunks; ++i) {
         const float* st = lds + stage * STAGE_DW;
-        stage ^= 1;
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
         if (kc == 0 && i > 0) { dump(); zero(); }
         __builtin_amdgcn_sched_barrier(0);
         rd(st, 1, fa1, fb1);
@@ -201,70 +199,48 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int n_c
 }
 
 // ------------------------------------------------------------------------------------------------ loader waves
-// Waves 4-7 issue EVERY global load of the workgroup: the operand chunks (global -> registers -> LDS, three register
-// sets: the loads of chunk i+3 are issued while chunk i+1, loaded two iterations ago, is written to its stage, so two
-// chunks are in flight at any time) and, riding in the same register sets, the residual rows of the epilogue passes that
-// run three iterations later, which they park in a small LDS ring.  Only loads, straight-line code: hipcc's counted
-// vmcnt waits are exact, and no wave ever waits for a store to be acknowledged.
-template <int P>
+// Waves 4-7: operand chunks by LDS-DMA (buffer_load ... lds, 16 B per lane; a wave-instruction fills 8 tile rows), three
+// stages: at iteration i the DMA of chunk i+2 goes into the stage chunk i-1 vacated, and the wave then waits -- counted,
+// vmcnt(8): the 8 pieces just issued stay in flight -- for chunk i+1 before the workgroup barrier.  No vector ALU work and
+// no registers: beside a dense fp32 MFMA stream another wave of the SIMD gets ~1 vector instruction per 50 cycles
+// (tools/micro/coissue.hip), so these waves issue nothing but the DMA itself.
+// The LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the SOURCE address: lane l of a piece
+// covers tile row r0 + l/8, physical chunk l%8, and fetches logical chunk (l%8) ^ ((row >> 1) & 7).
 __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigned tile0, int n_chunks, int hl) {
-    const int ld_row = hl >> 3, ld_c4 = hl & 7;
-    const int e_row = hl >> 5, e_c4 = hl & 31;      // the epilogue lane this lane fetches residual rows for
-    uint32_t aoff[4], boff[4];                      // byte offsets of this lane's 4 + 4 staged rows
-    uint32_t rbase = OOB;                           // byte offset of (row e_row, column 4 e_c4) of the PREVIOUS tile in y
-    int rrows = 0;                                  // valid rows of that tile
+    const int lane = hl & 63, lw = __builtin_amdgcn_readfirstlane(hl >> 6);
+    const int prow = lane >> 3;                                  // row inside a piece
+    uint32_t aoff[4], boff[4];                                   // byte offsets of this lane's source chunk, per piece
     auto set_tile = [&](unsigned t) {
         unsigned tm, tn;
         tile_coords(p, t, tm, tn);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            int m = (int)tm * BM + ld_row + 32 * q;
+            const int r = 32 * q + 8 * lw + prow;                // tile row of this lane in piece q (A and B alike)
+            const uint32_t ch = (uint32_t)((lane & 7) ^ ((r >> 1) & 7));
+            int m = (int)tm * BM + r;
             if (m > p.M - 1) m = p.M - 1;           // rows past the edge are clamped: their products are never stored
-            aoff[q] = ((uint32_t)m * (uint32_t)p.K + 4u * ld_c4) * 4u;
-            int n = (int)tn * BN + ld_row + 32 * q;
+            aoff[q] = ((uint32_t)m * (uint32_t)p.K + 4u * ch) * 4u;
+            int n = (int)tn * BN + r;
             if (n > p.N - 1) n = p.N - 1;
-            boff[q] = ((uint32_t)n * (uint32_t)p.K + 4u * ld_c4) * 4u;
-        }
-        if (t > tile0) {
-            tile_coords(p, t - 1, tm, tn);
-            const int n = (int)tn * BN + 4 * e_c4;
-            rrows = p.M - (int)tm * BM;
-            rbase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u : OOB;
+            boff[q] = ((uint32_t)n * (uint32_t)p.K + 4u * ch) * 4u;
         }
     };
-    // buffer form: per-lane row offset in voffset (changes per tile), the chunk's byte offset in soffset (scalar) -- no
-    // per-load address arithmetic on the vector unit, which these waves share with the MFMA stream
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)0x7fffffff, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)0x7fffffff, 0x00020000);
-    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.X), 0,
-                                                        p.residual ? (int)((int64_t)p.M * p.N * 4) : 0, 0x00020000);
-    auto gload = [&](int kc, f32x4 (&r)[8 + P]) {
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    auto dma = [&](int kc, int stage) {
         if (DBG & 1) return;
         const int so = kc * 128;
+        float* st = lds + stage * STAGE_DW + 8 * lw * BK;        // this wave's 8 rows of piece 0
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, aoff[q], so, 0));
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(st + 32 * q * BK), 16, aoff[q], so, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) r[4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, boff[q], so, 0));
-        // residual rows of the passes that run while chunk kc of this tile is in the MFMAs: e = (kc - 1) P + k of the
-        // previous tile (none during chunk 0, none past pass 15, none past row M: out-of-range offset, the load returns 0)
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            const int e = (kc - 1) * P + k, row = 8 * e + e_row;
-            const uint32_t off = (kc >= 1 && e < PASSES && row < rrows && rbase != OOB) ? rbase + (uint32_t)(8 * e) * (uint32_t)p.N * 4u : OOB;
-            r[8 + k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off, 0, 0));
-        }
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(st + (BM + 32 * q) * BK), 16, boff[q], so, 0, 0);
     };
-    const int st_off = ld_row * BK + 4 * (ld_c4 ^ ((ld_row >> 1) & 7));     // (row + 32 q keeps the swizzle key)
-    float* const R = lds + R_OFF_DW + 4 * hl;
-    auto lstore = [&](int stage, const f32x4 (&r)[8 + P]) {
-        float* st = lds + stage * STAGE_DW + st_off;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) *reinterpret_cast<f32x4*>(st + 32 * q * BK) = r[q];
-#pragma unroll
-        for (int k = 0; k < P; ++k) *reinterpret_cast<f32x4*>(R + (stage * P + k) * 1024) = r[8 + k];
-    };
-    // cursor (three chunks ahead of the matrix waves).  Past the workgroup's last chunk it stays put: loads and LDS writes
-    // are unconditional, a duplicate of the last chunk lands in the idle stage.
+    // cursor (two chunks ahead of the matrix waves).  Past the workgroup's last chunk it stays put: the DMA is
+    // unconditional (the counted wait needs a fixed number of pieces per iteration), a duplicate lands in an idle stage.
     unsigned ld_tile = tile0;
     int ld_kc = 0, ld_idx = 0;
     auto advance = [&]() {
@@ -273,104 +249,23 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
             if (++ld_kc == p.nk) { ld_kc = 0; ++ld_tile; set_tile(ld_tile); }
         }
     };
-    f32x4 s0[8 + P], s1[8 + P], s2[8 + P];
     set_tile(ld_tile);
-    gload(ld_kc, s0);
+    dma(ld_kc, 0);
     advance();
-    gload(ld_kc, s1);
+    dma(ld_kc, 1);
     advance();
-    gload(ld_kc, s2);
-    advance();
-    lstore(0, s0);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // chunk 0 has landed
     ws_barrier();
-    int stage = 1;                                  // LDS stage chunk i+1 goes to
-#ifdef MUMPY_WS_STAMP
-    unsigned long long t_work = 0, t_wait = 0, t_prev = __builtin_amdgcn_s_memtime();
-#endif
-    auto step = [&](f32x4 (&r_free)[8 + P], f32x4 (&r_next)[8 + P]) {
-        // chunk i is in the MFMAs.  r_free held chunk i (in LDS since the last iteration); r_next holds chunk i+1.
-        gload(ld_kc, r_free);
-        advance();
-        if (!(DBG & 4)) lstore(stage, r_next);
-        stage ^= 1;
-#ifdef MUMPY_WS_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-#endif
-        ws_barrier();
-#ifdef MUMPY_WS_STAMP
-        const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-        t_work += t1 - t_prev; t_wait += t2 - t1; t_prev = t2;
-#endif
-    };
-    int i = 0;
-    for (; i + 2 < n_chunks; i += 3) {
-        step(s0, s1);
-        step(s1, s2);
-        step(s2, s0);
-    }
-    if (i < n_chunks) step(s0, s1);
-    if (i + 1 < n_chunks) step(s1, s2);
-#ifdef MUMPY_WS_STAMP
-    if (hl == 0) { p.stamps[8 * blockIdx.x + 4] = t_work; p.stamps[8 * blockIdx.x + 5] = t_wait; }
-#endif
-    ws_barrier();
-}
-
-// ------------------------------------------------------------------------------------------------ epilogue waves
-// Waves 8-11: the previous tile's accumulator image -> y.  P = passes per chunk: the image of a tile is free during the
-// nk - 1 chunks that follow its dump, so P >= ceil(16 / (nk - 1)).  Pass e = image rows 8e + (hl >> 5), columns
-// 4 (hl & 31) .. + 3.  In the loop these waves touch global memory with stores only (predicated by an out-of-range
-// buffer offset), so they never wait on the memory counter; the one load, the tile's bias, is issued a chunk ahead.
-template <int P>
-__device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned tile0, int n_chunks, int hl) {
-    const float* const E = lds + E_OFF_DW;
-    const float* const R = lds + R_OFF_DW + 4 * hl;
-    const int e_row = hl >> 5, e_c4 = hl & 31;
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.M * p.N * 4), 0x00020000);
-    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.Y), 0, p.bias ? p.N * 4 : 0, 0x00020000);
-    unsigned cur_tile = tile0;                      // tile / chunk-in-tile of iteration i
-    int kc = 0, stage = 0;
-    uint32_t ybase = OOB;                           // byte offset of (row e_row, column 4 e_c4) of the previous tile in y
-    int yrows = 0;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, bias_next = {0.f, 0.f, 0.f, 0.f};
-    ws_barrier();
+    int stage = 2;                                               // stage of chunk i+2
 #ifdef MUMPY_WS_STAMP
     unsigned long long t_work = 0, t_wait = 0, t_prev = __builtin_amdgcn_s_memtime();
 #endif
     for (int i = 0; i < n_chunks; ++i) {
-        if (DBG & 2) {
-        } else if (kc == 0) {
-            // chunk 0 of a tile: its predecessor's image is being dumped.  Fetch that tile's bias now (used from the next
-            // chunk on: the only wait on a load in this role, once per tile, a chunk after the issue).
-            ybase = OOB;
-            uint32_t boff = OOB;
-            if (cur_tile > tile0 && !(DBG & 2)) {
-                unsigned tm, tn;
-                tile_coords(p, cur_tile - 1, tm, tn);
-                const int n = (int)tn * BN + 4 * e_c4;
-                yrows = p.M - (int)tm * BM;
-                if (n < p.N) { ybase = (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u; boff = (uint32_t)n * 4u; }
-            }
-            bias_next = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, boff, 0, 0));
-        } else {
-            if (kc == 1) bias4 = bias_next;
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                const int e = (kc - 1) * P + k, row = 8 * e + e_row;
-                const int ec = e < PASSES ? e : PASSES - 1;      // (pass past the image: any row, the store is dropped)
-                f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * ec + e_row) * BN + 4 * e_c4) + bias4;
-                if (p.act == MUMPY_ACT_GELU) {
-#pragma unroll
-                    for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
-                }
-                v += *reinterpret_cast<const f32x4*>(R + (stage * P + k) * 1024);
-                const uint32_t off = (e < PASSES && row < yrows && ybase != OOB) ? ybase + (uint32_t)(8 * e) * (uint32_t)p.N * 4u : OOB;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, off, 0, 0);
-            }
-        }
+        dma(ld_kc, stage);                                       // chunk i+2 -> the stage chunk i-1 was read from
+        advance();
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");        // chunk i+1 has landed
 #ifdef MUMPY_WS_STAMP
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         const unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
         ws_barrier();
@@ -378,34 +273,80 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
         const unsigned long long t2 = __builtin_amdgcn_s_memtime();
         t_work += t1 - t_prev; t_wait += t2 - t1; t_prev = t2;
 #endif
-        stage ^= 1;
-        if (++kc == p.nk) { kc = 0; ++cur_tile; }
     }
 #ifdef MUMPY_WS_STAMP
-    if (hl == 0) { p.stamps[8 * blockIdx.x + 6] = t_work; p.stamps[8 * blockIdx.x + 7] = t_wait; }
+    if (hl == 0) { p.stamps[8 * blockIdx.x + 4] = t_work; p.stamps[8 * blockIdx.x + 5] = t_wait; }
 #endif
-    ws_barrier();                                   // the last tile's accumulators are in LDS
-    if (DBG & 2) return;
-    {   // tail: the whole image of the last tile, nothing left to overlap with
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no DMA may outlive the workgroup's LDS allocation
+    ws_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------ epilogue waves
+// Waves 8-11: y tile = act(image + bias) + residual.  During chunk 0 of the next tile (while the matrix waves dump) they
+// issue the 16 residual loads + the bias load of the finished tile; during chunk 1 they pull the whole accumulator image
+// into registers (16 x ds_read_b128 per lane: rows 8e + (hl >> 5), columns 4 (hl & 31) .. + 3); then P passes per chunk
+// (P >= ceil(16 / (nk - 1))): bias, exact-erf GELU, residual, one 16-B store per lane -- ~60 vector instructions per
+// GELU pass, which fit the issue slots the MFMA stream leaves.  The pass code is unrolled with static register indices;
+// the chunks that remain of a tile only join the barrier.
+template <int P>
+__device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned tile0, int n_chunks, int hl) {
+    const float* const E = lds + E_OFF_DW;
+    const int e_row = hl >> 5, e_c4 = hl & 31;
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.M * p.N * 4), 0x00020000);
+    const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.Y), 0,
+                                                        p.residual ? (int)((int64_t)p.M * p.N * 4) : 0, 0x00020000);
+    const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.Y), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    constexpr int STEPS = PASSES / P;
+    f32x4 rv[PASSES], bias4;
+    uint32_t ybase = OOB;                           // byte offset of (row e_row, column 4 e_c4) of the tile in flight in y
+    int yrows = 0;                                  // its valid rows
+    const uint32_t row8 = 8u * (uint32_t)p.N * 4u;  // byte pitch of 8 rows of y
+    auto begin_tile = [&](unsigned t) {             // the tile whose image is being dumped: fetch its residual rows + bias
         unsigned tm, tn;
-        tile_coords(p, cur_tile - (kc == 0 ? 1u : 0u), tm, tn);
+        tile_coords(p, t, tm, tn);
         const int n = (int)tn * BN + 4 * e_c4;
-        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && n < p.N) b4 = *reinterpret_cast<const f32x4*>(p.bias + n);
-        for (int e = 0; e < PASSES; ++e) {
-            const int r = 8 * e + e_row, m = (int)tm * BM + r;
-            if (m < p.M && n < p.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(E + r * BN + 4 * e_c4) + b4;
-                if (p.act == MUMPY_ACT_GELU) {
+        yrows = p.M - (int)tm * BM;
+        ybase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u : OOB;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
-                }
-                const int64_t o = (int64_t)m * p.N + n;
-                if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + o);
-                *reinterpret_cast<f32x4*>(p.Y + o) = v;
-            }
+        for (int e = 0; e < PASSES; ++e) {
+            const uint32_t off = (ybase != OOB && 8 * e + e_row < yrows) ? ybase + (uint32_t)e * row8 : OOB;
+            rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off, 0, 0));
         }
+        bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, ybase != OOB ? (uint32_t)n * 4u : OOB, 0, 0));
+    };
+    auto pass = [&](int e) {                        // e is a compile-time constant at every call site
+        f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * e + e_row) * BN + 4 * e_c4) + bias4;
+        if (p.act == MUMPY_ACT_GELU) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
+        }
+        v += rv[e];
+        const uint32_t off = (ybase != OOB && 8 * e + e_row < yrows) ? ybase + (uint32_t)e * row8 : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, off, 0, 0);
+    };
+    ws_barrier();
+    const int n_tiles = n_chunks / p.nk;
+    for (int kc = 0; kc < p.nk; ++kc) ws_barrier();            // first tile: nothing to write out yet
+    if (DBG & 2) {
+        for (int i = p.nk; i < n_chunks; ++i) ws_barrier();
+        ws_barrier();
+        return;
     }
+    for (int t = 1; t < n_tiles; ++t) {
+        begin_tile(tile0 + t - 1);                  // chunk 0: the previous tile is being dumped
+        ws_barrier();
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {           // chunks 1 .. STEPS: P passes each
+#pragma unroll
+            for (int k = 0; k < P; ++k) pass(s * P + k);
+            ws_barrier();
+        }
+        for (int kc = 1 + STEPS; kc < p.nk; ++kc) ws_barrier();
+    }
+    begin_tile(tile0 + n_tiles - 1);
+    ws_barrier();                                   // the last tile's accumulators are in LDS
+#pragma unroll
+    for (int e = 0; e < PASSES; ++e) pass(e);
 }
 
 template <int P>
@@ -427,14 +368,14 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
         // (issue is arbitrated by priority, then age, and the matrix waves are the oldest): at equal priority a helper
         // iteration took ~6,300 cycles against the 4,096 of a chunk's MFMAs, and the matrix waves waited at the barrier
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(3);
-        if (wave < 8) loader_role<P>(p, lds, t0, n_chunks, tid - 256);
+        if (wave < 8) loader_role(p, lds, t0, n_chunks, tid - 256);
         else epilogue_role<P>(p, lds, t0, n_chunks, tid - 512);
     }
 }
 
 // eligibility of a shape for this kernel (the caller falls back to the tiled kernels of gemm.hip otherwise)
 inline bool eligible(int64_t M, int N, int K) {
-    return K % BK == 0 && K >= 5 * BK && N % 4 == 0 && M >= 1 && M * (int64_t)K * 4 < (1ll << 31) &&
+    return K % BK == 0 && K >= 3 * BK && N % 4 == 0 && M >= 1 && M * (int64_t)K * 4 < (1ll << 31) &&
            (int64_t)N * K * 4 < (1ll << 31) && M * (int64_t)N * 4 < (1ll << 31);
 }
 
@@ -465,7 +406,8 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     } while (0)
     if (need <= 1) MUMPY_WS_LAUNCH(1);
     else if (need <= 2) MUMPY_WS_LAUNCH(2);
-    else MUMPY_WS_LAUNCH(4);
+    else if (need <= 4) MUMPY_WS_LAUNCH(4);
+    else MUMPY_WS_LAUNCH(8);
 #undef MUMPY_WS_LAUNCH
     return 0;
 }
