@@ -700,7 +700,11 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0 || math_x2;      // the two-piece mode shares the three-piece planner
     act &= 0xff;
     // Large dense fp32 shapes: the persistent wave-specialised kernel (gemm_ws.h).  MUMPY_GEMM_WS=0 disables it, =1 forces
-    // it for every eligible shape (tuning); default: shapes that give every CU at least most of a round of 128x128 tiles.
+    // it for every eligible shape, =3 forces its split ("stream-K") schedule wherever a workspace is given (both: tuning).
+    // Default, fitted to same-device A/B runs of tools/gemm_shapes.py over the model's shapes: take it when whole 128x128
+    // tiles fill >= 86 % of the rounds they need (K >= 128), or -- with a workspace -- when an even split of the chunk
+    // sequence gives every CU >= 24 chunks and cuts a tile into <= 3 parts; leave the deep-K shapes with two or more tiles
+    // per CU to the tiled kernels (two co-resident workgroups hide each other's prologue and epilogue there: 121 TFLOP/s).
     if (!conv && rpb >= M && !math_bf16 && !math_x3 && gemm_ws::eligible(M, N, K)) {
         static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
         static int num_cu = 0;
@@ -711,10 +715,19 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
             else num_cu = NUM_CU;
         }
         const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        const double rounds = (double)tiles / num_cu;
-        const bool balanced = tiles >= (int64_t)(0.85 * num_cu) && (rounds - (int64_t)rounds == 0.0 || rounds - (int64_t)rounds >= 0.8 || rounds >= 6.0);
-        if (ws_mode == 1 || (ws_mode == 2 && balanced && K >= 384)) {
-            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s)) return rc;
+        const int nk = K / 32;
+        const double rounds = (double)tiles / num_cu, eff = rounds / (double)((tiles + num_cu - 1) / num_cu);
+        const double per_cu = (double)tiles * nk / num_cu;                 // chunks per CU under an even split
+        const bool have_ws = ws && ws_bytes >= gemm_ws::workspace_bytes(num_cu);
+        int how = 0;                                                        // 0: tiled kernels, 1: whole tiles, 2: split
+        if (ws_mode == 1) how = 1;
+        else if (ws_mode == 3) how = have_ws ? 2 : 1;
+        else if (ws_mode == 2) {
+            if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.86 && K >= 128 && !(K >= 1024 && rounds >= 1.8)) how = 1;
+            else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
+        }
+        if (how) {
+            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0)) return rc;
             MUMPY_CHECK_LAUNCH("linear(ws)");
             return 0;
         }
@@ -822,7 +835,15 @@ extern "C" int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
     const Plan p = make_plan(M, N, K, true), q = make_plan(M, N, K, true, true);     // either matrix-math mode
     const int ks = p.ksplit > q.ksplit ? p.ksplit : q.ksplit;
-    return ks > 1 ? (int64_t)ks * M * N * (int64_t)sizeof(float) : 0;
+    int64_t bytes = ks > 1 ? (int64_t)ks * M * N * (int64_t)sizeof(float) : 0;
+    // the persistent kernel's split schedule (gemm_ws.h): flags + one 64-KB slab per workgroup, when the shape may take it
+    if (gemm_ws::eligible(M, N, K)) {
+        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        const double per_cu = (double)tiles * (K / 32) / NUM_CU;
+        const int64_t need = gemm_ws::workspace_bytes(2 * NUM_CU);          // (room for devices with more CUs than the model)
+        if (per_cu >= 16.0 && bytes < need) bytes = need;
+    }
+    return bytes;
 }
 
 extern "C" int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,

@@ -51,7 +51,10 @@ struct Params {
     int nk;                // K / 32
     unsigned gm, gn;       // tiles along M, N
     unsigned tiles;        // gm * gn
-    unsigned sched_S, sched_SN;   // experiment: > 0 = lockstep 8x4 super-tiles per XCD (S per XCD, SN across N)
+    unsigned units;        // tiles * nk: the workgroups split this chunk sequence evenly (split tiles: "stream-K")
+    int lmin;              // shortest allowed head part of a split tile (chunks)
+    unsigned* flags;       // [grid] arrival flags of the partial slabs (zeroed by the launcher), or null: whole tiles only
+    float* slabs;          // [grid][128*128] partial accumulator images of split tiles
 #ifdef MUMPY_WS_STAMP
     unsigned long long* stamps;   // diagnostics build: [block][8] cycle sums
 #endif
@@ -62,13 +65,6 @@ struct Params {
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __device__ __forceinline__ void tile_coords(const Params& p, unsigned t, unsigned& tm, unsigned& tn) {
-    if (p.sched_S) {       // virtual id = b' * S + s: workgroup b' = 32 x + j is tile j of the s-th super-tile of XCD x
-        const unsigned b = t / p.sched_S, sq = t - b * p.sched_S, x = b >> 5, j = b & 31, id = sq * 8 + x;
-        const unsigned sm = id / p.sched_SN, sn = id - sm * p.sched_SN;
-        tm = sm * 8 + (j >> 2);
-        tn = sn * 4 + (j & 3);
-        return;
-    }
     // order (N-group, M, N-in-group): the tiles one XCD works on share a few x row panels and a narrow slice of W
     const unsigned full = (p.gn / NG) * NG;
     if (t < p.gm * full) {
@@ -82,11 +78,23 @@ __device__ __forceinline__ void tile_coords(const Params& p, unsigned t, unsigne
     }
 }
 
+// First chunk of workgroup b (b = G: one past the end).  Whole-tile mode: tile boundaries.  Split mode: an even share of
+// the chunk sequence, moved to the tile boundary when it would leave a head part shorter than lmin chunks (the epilogue of
+// the tile before it needs that many chunks to run under) or a tail part of one or two chunks (not worth a slab).
+__device__ __host__ __forceinline__ unsigned first_chunk(unsigned b, unsigned G, unsigned tiles, unsigned units, int nk, int lmin, bool split) {
+    if (!split) return (unsigned)(((uint64_t)b * tiles) / G) * (unsigned)nk;
+    unsigned u = (unsigned)(((uint64_t)b * units) / G);
+    const unsigned r = u % (unsigned)nk;
+    if (r != 0 && r < (unsigned)lmin) u -= r;
+    else if (r != 0 && (unsigned)nk - r < 3u) u += (unsigned)nk - r;
+    return u;
+}
+
 // ------------------------------------------------------------------------------------------------ matrix waves
 // LDS stage image: [row][32 floats], 16-B chunk x of row R stored at chunk x ^ ((R >> 1) & 7): 16 consecutive rows read
 // the same logical chunk from 16 distinct 16-B slots of the 256-B bank row (conflict-free ds_read_b128), and the 8 lanes
 // that write one row cover its 128 bytes.
-__device__ __forceinline__ void matrix_role(const Params& p, float* lds, int n_chunks, int wave, int lane) {
+__device__ __forceinline__ void matrix_role(const Params& p, float* lds, int kc0, int n_chunks, int wave, int lane) {
     const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
     const int sw = (c >> 1) & 7;
     int a_off[4], b_off[4];                          // dword offsets of this lane's chunk (4h + q) in tile row c
@@ -141,7 +149,7 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int n_c
     const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
 #endif
     rd(lds, 0, fa0, fb0);
-    int kc = 0, stage = 0;
+    int kc = kc0, stage = 0;
     // issue order, pinned: each fragment read sits behind one MFMA of the previous sub-step, so its latency is covered
     // by the 15 MFMAs (960 matrix-pipe cycles) that follow; hipcc's own order put the reads at the END of a sub-step,
     // one MFMA ahead of their first use
@@ -206,7 +214,7 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int n_c
 // (tools/micro/coissue.hip), so these waves issue nothing but the DMA itself.
 // The LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the SOURCE address: lane l of a piece
 // covers tile row r0 + l/8, physical chunk l%8, and fetches logical chunk (l%8) ^ ((row >> 1) & 7).
-__device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigned tile0, int n_chunks, int hl) {
+__device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigned tile0, int kc0, int n_chunks, int hl) {
     const int lane = hl & 63, lw = __builtin_amdgcn_readfirstlane(hl >> 6);
     const int prow = lane >> 3;                                  // row inside a piece
     uint32_t aoff[4], boff[4];                                   // byte offsets of this lane's source chunk, per piece
@@ -242,7 +250,7 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
     // cursor (two chunks ahead of the matrix waves).  Past the workgroup's last chunk it stays put: the DMA is
     // unconditional (the counted wait needs a fixed number of pieces per iteration), a duplicate lands in an idle stage.
     unsigned ld_tile = tile0;
-    int ld_kc = 0, ld_idx = 0;
+    int ld_kc = kc0, ld_idx = 0;
     auto advance = [&]() {
         if (ld_idx + 1 < n_chunks) {
             ++ld_idx;
@@ -289,30 +297,34 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
 // GELU pass, which fit the issue slots the MFMA stream leaves.  The pass code is unrolled with static register indices;
 // the chunks that remain of a tile only join the barrier.
 template <int P>
-__device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned tile0, int n_chunks, int hl) {
+__device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned b, unsigned G, unsigned u0, unsigned u1, int hl) {
     const float* const E = lds + E_OFF_DW;
     const int e_row = hl >> 5, e_c4 = hl & 31;
+    const unsigned nk = (unsigned)p.nk;
+    const bool split = p.flags != nullptr;
     const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.M * p.N * 4), 0x00020000);
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.Y), 0,
                                                         p.residual ? (int)((int64_t)p.M * p.N * 4) : 0, 0x00020000);
     const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.Y), 0, p.bias ? p.N * 4 : 0, 0x00020000);
+    // this workgroup's slab (a raw 128x128 image, rows of 512 B): where a part that does not own its tile goes
+    const auto rs_s = __builtin_amdgcn_make_buffer_rsrc(split ? p.slabs + (size_t)b * E_DW : p.Y, 0, split ? E_DW * 4 : 0, 0x00020000);
     constexpr int STEPS = PASSES / P;
     f32x4 rv[PASSES], bias4;
-    uint32_t ybase = OOB;                           // byte offset of (row e_row, column 4 e_c4) of the tile in flight in y
-    int yrows = 0;                                  // its valid rows
+    uint32_t yo[PASSES];                            // byte offsets of this lane's 16 output rows in y (tile in flight)
     const uint32_t row8 = 8u * (uint32_t)p.N * 4u;  // byte pitch of 8 rows of y
+    // Rows past M need no predicate: their offsets are past the end of the buffer (num_records = M N 4) and the access is
+    // dropped by the range check; columns past N start from the OOB offset.
     auto begin_tile = [&](unsigned t) {             // the tile whose image is being dumped: fetch its residual rows + bias
         unsigned tm, tn;
         tile_coords(p, t, tm, tn);
         const int n = (int)tn * BN + 4 * e_c4;
-        yrows = p.M - (int)tm * BM;
-        ybase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u : OOB;
+        const uint32_t ybase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u : OOB;
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
-            const uint32_t off = (ybase != OOB && 8 * e + e_row < yrows) ? ybase + (uint32_t)e * row8 : OOB;
-            rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, off, 0, 0));
+            yo[e] = ybase + (uint32_t)e * row8;
+            rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, yo[e], 0, 0));
         }
-        bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, ybase != OOB ? (uint32_t)n * 4u : OOB, 0, 0));
+        bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n < p.N ? (uint32_t)n * 4u : OOB, 0, 0));
     };
     auto pass = [&](int e) {                        // e is a compile-time constant at every call site
         f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * e + e_row) * BN + 4 * e_c4) + bias4;
@@ -321,32 +333,120 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
             for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
         }
         v += rv[e];
-        const uint32_t off = (ybase != OOB && 8 * e + e_row < yrows) ? ybase + (uint32_t)e * row8 : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, yo[e], 0, 0);
     };
+    const uint32_t soff = ((uint32_t)e_row * BN + 4u * e_c4) * 4u;
+    auto pass_part = [&](int e) {                   // raw partial sums -> this workgroup's slab (always in range)
+        const f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * e + e_row) * BN + 4 * e_c4);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_s, soff, e * (8 * BN * 4), 0);
+    };
+    // publish the slab: every storing wave has waited for its stores and passed a workgroup barrier before this is called
+    // by ONE lane; agent-scope release (L2 write-back), then the flag (cdna guide, Guideline 16: plain payload + release
+    // fence + relaxed agent flag)
+    auto publish = [&]() {
+        if (hl == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(p.flags + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
     ws_barrier();
-    const int n_tiles = n_chunks / p.nk;
-    for (int kc = 0; kc < p.nk; ++kc) ws_barrier();            // first tile: nothing to write out yet
+    // segments of this workgroup: [u0, end of u0's tile), whole tiles, [start of u1's tile, u1)
+    unsigned prev_t = u0 / nk;                      // the segment whose image is (about to be) in LDS
+    bool prev_part = (u0 % nk) != 0;                // it starts inside its tile: another workgroup owns the tile
+    unsigned u = (prev_t + 1) * nk < u1 ? (prev_t + 1) * nk : u1;
+    for (unsigned c = u0; c < u; ++c) ws_barrier(); // first segment: nothing to write out yet
     if (DBG & 2) {
-        for (int i = p.nk; i < n_chunks; ++i) ws_barrier();
+        for (; u < u1; ++u) ws_barrier();
         ws_barrier();
         return;
     }
-    for (int t = 1; t < n_tiles; ++t) {
-        begin_tile(tile0 + t - 1);                  // chunk 0: the previous tile is being dumped
-        ws_barrier();
+    // every further segment is >= 1 + STEPS chunks long (first_chunk's rule): room for the previous segment's epilogue.
+    // Only the FIRST segment can be a part of a tile owned elsewhere: its write-out (raw, to the slab) is peeled.
+    if (u < u1 && prev_part) {
+        const unsigned end = u + nk < u1 ? u + nk : u1;
+        ws_barrier();                               // chunk 0: the previous segment is being dumped
 #pragma unroll
-        for (int s = 0; s < STEPS; ++s) {           // chunks 1 .. STEPS: P passes each
+        for (int st = 0; st < STEPS; ++st) {
 #pragma unroll
-            for (int k = 0; k < P; ++k) pass(s * P + k);
+            for (int k = 0; k < P; ++k) pass_part(st * P + k);
+            if (st == STEPS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             ws_barrier();
         }
-        for (int kc = 1 + STEPS; kc < p.nk; ++kc) ws_barrier();
+        publish();
+        for (unsigned c = u + 1 + STEPS; c < end; ++c) ws_barrier();
+        prev_t = u / nk;
+        prev_part = false;
+        u = end;
     }
-    begin_tile(tile0 + n_tiles - 1);
-    ws_barrier();                                   // the last tile's accumulators are in LDS
+    while (u < u1) {
+        const unsigned end = u + nk < u1 ? u + nk : u1;
+        begin_tile(prev_t);
+        ws_barrier();
 #pragma unroll
-    for (int e = 0; e < PASSES; ++e) pass(e);
+        for (int st = 0; st < STEPS; ++st) {       // chunks 1 .. STEPS: P passes each
+#pragma unroll
+            for (int k = 0; k < P; ++k) pass(st * P + k);
+            ws_barrier();
+        }
+        for (unsigned c = u + 1 + STEPS; c < end; ++c) ws_barrier();
+        prev_t = u / nk;
+        u = end;
+    }
+    // tail: the last segment, nothing left to overlap with
+    const bool head = split && !prev_part && (u1 % nk) != 0;     // this workgroup owns a tile whose later chunks ran elsewhere
+    if (!prev_part) begin_tile(prev_t);
+    ws_barrier();                                   // the last segment's accumulators are in LDS
+    if (prev_part) {
+#pragma unroll
+        for (int e = 0; e < PASSES; ++e) {
+            pass_part(e);
+            if (e % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");      // (the other roles have left: 4 waves)
+        publish();
+        return;
+    }
+    if (head) {
+        // the other parts of the tile are the FIRST segments of the following workgroups (they finished long ago: a
+        // first segment depends on nothing, so this wait cannot deadlock; bounded all the same).  One lane polls, then an
+        // agent-scope acquire makes the slabs visible to this CU; the flags are put back to 0 for the next launch.
+        const unsigned tile_end = (prev_t + 1) * nk;
+        if (hl == 0) {
+            for (unsigned b2 = b + 1; b2 < G; ++b2) {
+                const unsigned f0 = first_chunk(b2, G, p.tiles, p.units, p.nk, p.lmin, true);
+                if (f0 >= tile_end) break;
+                if (first_chunk(b2 + 1, G, p.tiles, p.units, p.nk, p.lmin, true) == f0) continue;        // empty workgroup
+                unsigned spins = 0;
+                while (__hip_atomic_load(p.flags + b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24))
+                    __builtin_amdgcn_s_sleep(8);
+                __hip_atomic_store(p.flags + b2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // sum the parts in chunk order into the image (fixed order: bitwise reproducible)
+        float* const Ew = lds + E_OFF_DW;
+        for (unsigned b2 = b + 1; b2 < G; ++b2) {
+            const unsigned f0 = first_chunk(b2, G, p.tiles, p.units, p.nk, p.lmin, true);
+            if (f0 >= tile_end) break;
+            if (first_chunk(b2 + 1, G, p.tiles, p.units, p.nk, p.lmin, true) == f0) continue;
+            const float* sl = p.slabs + (size_t)b2 * E_DW + e_row * BN + 4 * e_c4;
+#pragma unroll 4
+            for (int e = 0; e < PASSES; ++e) {
+                f32x4* d = reinterpret_cast<f32x4*>(Ew + (8 * e + e_row) * BN + 4 * e_c4);
+                *d += *reinterpret_cast<const f32x4*>(sl + 8 * e * BN);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int e = 0; e < PASSES; ++e) {
+        pass(e);
+        if (e % 4 == 3) __builtin_amdgcn_sched_barrier(0);       // (keeps hipcc from hoisting all 16 image reads: spills)
+    }
 }
 
 template <int P>
@@ -354,22 +454,24 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // persistent schedule: workgroup b' owns the contiguous tile range [b' T / G, (b'+1) T / G); b' is the XCD-major
+    // persistent schedule: workgroup b' owns a contiguous run of the (tile, chunk) sequence; b' is the XCD-major
     // renumbering of blockIdx.x (workgroups are dealt round-robin over the 8 XCDs), so an XCD's L2 sees neighbouring tiles
     const unsigned G = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = G >> 3, r8 = G & 7;
     const unsigned b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
-    unsigned t0 = (unsigned)(((uint64_t)b * p.tiles) / G), t1 = (unsigned)(((uint64_t)(b + 1) * p.tiles) / G);
-    if (p.sched_S) { t0 = b * p.sched_S; t1 = t0 + p.sched_S; }
-    const int n_chunks = (int)(t1 - t0) * p.nk;
+    const bool split = p.flags != nullptr;
+    const unsigned u0 = first_chunk(b, G, p.tiles, p.units, p.nk, p.lmin, split);
+    const unsigned u1 = first_chunk(b + 1, G, p.tiles, p.units, p.nk, p.lmin, split);
+    const int n_chunks = (int)(u1 - u0);
     if (n_chunks == 0) return;
-    if (wave < 4) matrix_role(p, lds, n_chunks, wave, lane);
+    const unsigned t0 = u0 / (unsigned)p.nk;
+    const int kc0 = (int)(u0 - t0 * (unsigned)p.nk);
+    if (wave < 4) matrix_role(p, lds, kc0, n_chunks, wave, lane);
     else {
-        // the other roles' vector instructions must not queue behind the matrix wave's MFMA stream on the shared SIMD
-        // (issue is arbitrated by priority, then age, and the matrix waves are the oldest): at equal priority a helper
-        // iteration took ~6,300 cycles against the 4,096 of a chunk's MFMAs, and the matrix waves waited at the barrier
+        // (priority: no measurable effect either way beside an fp32 MFMA stream -- tools/micro/coissue.hip; kept so that
+        // the few instructions of these roles are not additionally delayed by arbitration)
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(3);
-        if (wave < 8) loader_role(p, lds, t0, n_chunks, tid - 256);
-        else epilogue_role<P>(p, lds, t0, n_chunks, tid - 512);
+        if (wave < 8) loader_role(p, lds, t0, kc0, n_chunks, tid - 256);
+        else epilogue_role<P>(p, lds, b, G, u0, u1, tid - 512);
     }
 }
 
@@ -379,20 +481,42 @@ inline bool eligible(int64_t M, int N, int K) {
            (int64_t)N * K * 4 < (1ll << 31) && M * (int64_t)N * 4 < (1ll << 31);
 }
 
+// workspace for the split schedule: arrival flags + one slab per workgroup
+inline int64_t workspace_bytes(int num_cu) { return 4096 + (int64_t)num_cu * E_DW * 4; }
+
 inline int launch(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
-                  int K, int act, int num_cu, hipStream_t s, void* stamps = nullptr, int lockstep = 0) {
+                  int K, int act, int num_cu, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0, int force_split = -1,
+                  void* stamps = nullptr) {
     Params p;
     p.X = x; p.W = W; p.bias = bias; p.residual = residual; p.Y = y;
     p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / BK;
     p.gm = (unsigned)((M + BM - 1) / BM); p.gn = (unsigned)((N + BN - 1) / BN);
     p.tiles = p.gm * p.gn;
+    p.units = p.tiles * (unsigned)p.nk;
 #ifdef MUMPY_WS_STAMP
     p.stamps = static_cast<unsigned long long*>(stamps);
 #endif
-    unsigned grid = p.tiles < (unsigned)num_cu ? p.tiles : (unsigned)num_cu;
-    p.sched_S = p.sched_SN = 0;
-    if (lockstep && p.gm % 8 == 0 && p.gn % 4 == 0 && (p.tiles / 32) % 8 == 0) { p.sched_SN = p.gn / 4; p.sched_S = p.tiles / 32 / 8; grid = 256; }
     const int need = (PASSES + p.nk - 2) / (p.nk - 1);
+    int P = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    // split tiles over workgroups when whole tiles would leave the last round of CUs under-used (and the caller gave a
+    // workspace): every workgroup then gets the same number of chunks, at the price of one slab round trip per split tile
+    const double rounds = (double)p.tiles / num_cu;
+    const double eff = rounds / (double)((p.tiles + num_cu - 1) / num_cu);           // CU utilisation of whole-tile rounds
+    bool split = ws && ws_bytes >= workspace_bytes(num_cu) && eff < 0.93 && p.units >= 16u * (unsigned)num_cu;
+    if (force_split >= 0) split = force_split && ws && ws_bytes >= workspace_bytes(num_cu);
+    // a head part must leave room for the previous tile's epilogue (1 + 16 / P chunks): more passes per chunk keep that
+    // short, so that the even split is not rounded away
+    if (split && P < 4) P = 4;
+    p.lmin = 1 + PASSES / P;
+    unsigned grid = p.tiles < (unsigned)num_cu ? p.tiles : (unsigned)num_cu;
+    p.flags = nullptr; p.slabs = nullptr;
+    if (split) {
+        grid = (unsigned)num_cu;
+        p.flags = static_cast<unsigned*>(ws);
+        p.slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + 4096);
+        hipError_t e = hipMemsetAsync(p.flags, 0, 4096, s);
+        if (e != hipSuccess) { set_error("gemm_ws: flag reset failed: %s", hipGetErrorString(e)); return (int)e; }
+    }
 #define MUMPY_WS_LAUNCH(P_)                                                                                             \
     do {                                                                                                                \
         static bool attr_set = false;                                                                                   \
@@ -404,9 +528,9 @@ inline int launch(const float* x, const float* W, const float* bias, const float
         }                                                                                                               \
         hipLaunchKernelGGL(gemm_ws_kernel<P_>, dim3(grid), dim3(768), LDS_BYTES, s, p);                                 \
     } while (0)
-    if (need <= 1) MUMPY_WS_LAUNCH(1);
-    else if (need <= 2) MUMPY_WS_LAUNCH(2);
-    else if (need <= 4) MUMPY_WS_LAUNCH(4);
+    if (P == 1) MUMPY_WS_LAUNCH(1);
+    else if (P == 2) MUMPY_WS_LAUNCH(2);
+    else if (P == 4) MUMPY_WS_LAUNCH(4);
     else MUMPY_WS_LAUNCH(8);
 #undef MUMPY_WS_LAUNCH
     return 0;

@@ -67,7 +67,7 @@ int main(int argc, char** argv) {
     CK(hipGetDeviceProperties(&prop, 0));
     dev_cu = prop.multiProcessorCount;
     const int grid_override = getenv("WS_GRID") ? atoi(getenv("WS_GRID")) : 0;
-    const int lockstep = getenv("WS_LOCKSTEP") ? atoi(getenv("WS_LOCKSTEP")) : 0;
+    const int force_split = getenv("WS_SPLIT") ? atoi(getenv("WS_SPLIT")) : -1;
     const int reps = getenv("WS_REPS") ? atoi(getenv("WS_REPS")) : 20;
     printf("%s, %d CUs, LDS %d B per workgroup, dbg %d\n", prop.name, dev_cu, mumpy::gemm_ws::LDS_BYTES, mumpy::gemm_ws::DBG);
     hipStream_t s;
@@ -84,6 +84,10 @@ int main(int argc, char** argv) {
         printf("bare MFMA loop on this device: %.1f TF\n", 256.0 * 4 * iters * 4 * 4096.0 / (ms * 1e-3) / 1e12);
         CK(hipFree(o));
     }
+    void* wsp = nullptr;
+    const int64_t wsb = mumpy::gemm_ws::workspace_bytes(dev_cu);
+    CK(hipMalloc(&wsp, wsb));
+    CK(hipMemset(wsp, 0xff, wsb));       // (the launcher must not rely on the workspace's contents)
     unsigned long long* stamps = nullptr;
 #ifdef MUMPY_WS_STAMP
     CK(hipMalloc(&stamps, 512 * 8 * 8));
@@ -100,7 +104,7 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(Y, 0xff, ny * 4, s));
         if (!mumpy::gemm_ws::eligible(sh.M, sh.N, sh.K)) { printf("%-10s %d %d %d not eligible\n", sh.tag, sh.M, sh.N, sh.K); continue; }
         const int cu = grid_override ? grid_override : dev_cu;
-        if (mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, stamps, lockstep)) return 1;
+        if (mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps)) return 1;
         CK(hipGetLastError());
         ref_kernel<<<dim3((sh.N + 255) / 256, sh.M), 256, 0, s>>>(X, W, B, sh.res ? R : nullptr, Yr, sh.M, sh.N, sh.K, sh.act);
         CK(hipStreamSynchronize(s));
@@ -116,9 +120,9 @@ int main(int argc, char** argv) {
         }
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, stamps, lockstep);
+        for (int i = 0; i < 3; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps);
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, stamps, lockstep);
+        for (int i = 0; i < reps; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps);
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         float ms = 0;
