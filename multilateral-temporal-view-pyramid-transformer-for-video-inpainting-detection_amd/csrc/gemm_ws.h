@@ -1,22 +1,33 @@
 // gemm_ws.h — persistent, wave-specialised fp32 GEMM for the large dense nn.Linear shapes of the path
 // (swin:46-49,142,164; blocks:27-33,57-71): y = act(x W^T + bias) + residual on v_mfma_f32_32x32x2_f32.
 //
-// One 512-thread workgroup per CU, looping over 128x128 output tiles:
-//   * waves 0-3 ("matrix waves", one per SIMD, 64x64 of the tile each) do nothing but ds_read_b128 fragment reads and
-//     MFMAs: per 8-deep K sub-step 4 reads feed 16 MFMAs (1024 matrix-pipe cycles), so the pipe is issued back to back by
-//     ONE wave per SIMD; the only synchronisation is one s_barrier per 32-deep chunk, placed in the middle of the chunk's
-//     last 16 MFMAs (the MFMA ahead of it is still executing while the wave sits in the barrier);
-//   * waves 4-7 ("helper waves") stage the operands (global -> registers -> LDS, three register sets, so two chunks of
-//     loads are always in flight) and run the epilogue of the PREVIOUS tile from an LDS image of its accumulators: bias,
-//     exact-erf GELU, residual, 16-B row-contiguous stores -- all under the next tile's MFMAs.  The matrix waves pay ~300
-//     cycles per tile to dump their 64 accumulator registers to LDS; prologue, epilogue and store latency leave the matrix
-//     pipe's critical path, which is what held the one-role kernels of gemm.hip at ~70 % matrix-pipe occupancy.
-// The helper's loop body is STRAIGHT-LINE code: every load and store is issued every iteration, predicated by an
-// out-of-range buffer offset instead of a branch, and the residual / bias operands of an epilogue pass are fetched one
-// iteration ahead.  vmcnt retires in issue order, so one wait on a freshly issued load (or a conservative vmcnt(0) at a
-// control-flow join, which is what hipcc emits after a branch that contains a memory operation) would drain the two
-// chunks of staging loads in flight and put the memory latency on the barrier the matrix waves wait at: measured, the
-// branchy first version ran 84 TFLOP/s where its matrix waves alone reach 126.
+// What shaped it (all measured on MI355X, tools/micro/):
+//   * the fp32 MFMA executes on the vector ALU: in ONE wave every other instruction is serialised with it -- a v_fma costs
+//     ~5 cycles of the 64-cycle MFMA period, a v_exp ~8.5, a ds_read_b128 ~10-15 (samewave.hip: 64.0 / 73 / 86 / 106 / 152
+//     cycles per MFMA with 0 / 1 / 4 / 8 / 16 v_fma behind each) -- there are no free issue slots to hide staging or
+//     epilogue work in, which is why the one-role kernels of gemm.hip sit at ~70 % matrix-pipe occupancy;
+//   * ANOTHER wave of the same SIMD does not slow a back-to-back MFMA stream at all (still 64.0 cycles per MFMA), but it
+//     only gets the bubbles: ~1 vector instruction per 49 cycles, ~1 LDS read per 150, whatever its priority (coissue.hip).
+// So: one 768-thread workgroup per CU, three roles, one wave of each per SIMD, looping over 128x128 output tiles:
+//   * waves 0-3, "matrix": 64x64 of the tile each; nothing but ds_read_b128 fragment reads and MFMAs (per 8-deep K
+//     sub-step 4 reads feed 16 MFMAs) and ONE s_barrier per 32-deep chunk, placed in the middle of the chunk's last 16
+//     MFMAs.  4,350 cycles per chunk against 4,096 of pure MFMA issue.  At a tile's end they dump the 64 accumulator
+//     registers to an LDS image (~300 cycles) and go on with the next tile;
+//   * waves 4-7, "loader": operand chunks by LDS-DMA (buffer_load ... lds), three stages, two chunks in flight, a counted
+//     vmcnt(8) before the barrier.  No vector-ALU work, no registers;
+//   * waves 8-11, "epilogue": the previous tile's image -> bias, exact-erf GELU, residual, 16-B row-contiguous stores,
+//     a few passes per chunk under the next tile's MFMAs (their ~60 vector instructions per GELU pass live in the
+//     bubbles); residual rows and bias are fetched a chunk ahead.  Rows / columns past the matrix edge are predicated by
+//     the buffer range check, not by branches.
+// Schedule: persistent; workgroup b' (XCD-major renumbering) owns a contiguous run of the (tile, chunk) sequence.  Whole
+// tiles, or -- "split" -- an even share of chunks each: a tile cut by a boundary is finished by the workgroup that holds
+// its FIRST chunks (its last segment), the others write raw partial images to per-workgroup slabs in the caller's
+// workspace and raise a flag (agent-scope release); the owner acquires, adds the slabs in chunk order (bitwise
+// reproducible) and runs the epilogue.  A part is always the first segment of its workgroup, which depends on nothing, so
+// the owner's wait cannot deadlock.
+// Measured (one device, bare MFMA loop 137-141 TFLOP/s; the tiled kernels of gemm.hip in brackets): M=7840 N=2048 K=512
+// +GELU 146 us = 113 TFLOP/s [176-180 us]; N=512 K=2048 +residual 149 us [159-165]; N=1536 113 us [132]; M=125440 N=512
+// K=128 +GELU 155 us [215]; M=1960 N=3072 K=768 (1.5 rounds of tiles, split) 93 us [104].  Matrix waves alone 116-120.
 // LDS: 3 stages x 256 rows x 32 dwords, XOR-swizzled 16-B chunks (98,304 B) + the 128x128 accumulator image (65,536 B)
 // = 163,840 B, the whole CU.
 #pragma once
