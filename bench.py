@@ -62,6 +62,9 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement reported beside the fp32 headline")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="launch-path rehearsal without a GPU: ranks, rendezvous, barrier, the metric all-reduce and the JSON "
+                         "line are real, the forward is replaced by a sleep (CPU tests; MUMPY_BENCH_BACKEND=gloo)")
     ap.add_argument("--cpu-sample-batch", type=int, default=8)
     return ap.parse_args()
 
@@ -189,11 +192,74 @@ def cpu_baseline(frames, sample_b):
                       f"({t:.2f} s per pass)"}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` invoked plainly (no torch.distributed.run): start N fresh child processes, one rank per
+    GPU, and relay rank 0's JSON line.  Children, never a re-exec: this parent has not touched the GPU and never will
+    (replaces the reference's in-process nn.DataParallel fan-out, test.py:56-58)."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+
+
+def rehearse(args, world, rank):
+    """The N-rank launch path with the forward replaced by a sleep: same rendezvous, barriers, metric all-reduce,
+    max-over-ranks timing and JSON line as the real run.  Needs no GPU (gloo)."""
+    from mumpy_hip import distributed as D
+    backend = os.environ.get("MUMPY_BENCH_BACKEND", "gloo")
+    D.init_process_group(backend, None)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001)
+    metric = D.all_reduce_metric(torch.tensor([0.5 * args.batch, 0.25 * args.batch, float(args.batch)], dtype=torch.float64))
+    if world > 1:
+        dist.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, None)
+    if rank == 0:
+        print(json.dumps({"metric": "clips/sec fwd (B=8,T=5,224x224)", "value": None, "unit": "clips/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none",
+                          "rehearsal": True, "config": {"workload": "launch-path rehearsal (no forward)", "global_batch": args.batch * world,
+                                                        "parallelism": f"batch-sharded x{world}, one metric all-reduce"},
+                          "eval_metric": {"f1": float(metric[0] / metric[2]), "iou": float(metric[1] / metric[2]), "clips": int(metric[2])}}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # first statement, before anything can initialise a GPU: settle the launch.  Under torch.distributed.run the
+    # environment carries the rank; a plain `python bench.py --gpus N` fans out into N children here.
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:
+            return spawn_ranks(args)
+        world, rank, local = 1, 0, 0
+    else:
+        world = int(os.environ["WORLD_SIZE"])
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with `python -m torch.distributed.run "
+                             f"--nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...` or plainly as `python bench.py --gpus {args.gpus}`")
+    if args.rehearse:
+        return rehearse(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP kernels are the only implementation (no CPU path)")
     # MUMPY_BENCH_BACKEND=gloo rehearses the N>1 launch path on a box with fewer GPUs than ranks (ranks share devices);
@@ -207,7 +273,6 @@ def main():
     torch.set_num_threads(max(1, min(16, (os.cpu_count() or 16) // max(world, 1))))
     from mumpy_hip import distributed as D
     D.init_process_group(backend, dev)                       # "nccl" = RCCL over xGMI (no-op at world 1)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run"
 
     from models.decoder.decoder import Decoder
     from models.encoder.encoder import Encoder

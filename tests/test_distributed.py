@@ -70,3 +70,33 @@ def test_micro_batch_slices_cover_and_balance():
             assert max(sizes) - min(sizes) <= 1
     with pytest.raises(ValueError):
         micro_batch_slice(8, 2, 2)
+
+
+def test_bench_plain_multi_gpu_invocation_spawns_ranks():
+    """`python bench.py --gpus 2` invoked plainly (no torch.distributed.run) must fan out into two rank processes itself
+    and print ONE JSON line with n_gpus 2.  --rehearse swaps the forward for a sleep, so the launch path (spawn,
+    rendezvous on 127.0.0.1, barrier, metric all-reduce, max-over-ranks) runs here on CPU over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["MUMPY_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]       # (gloo itself prints a connection note on stdout)
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["rehearsal"] is True
+    assert out["eval_metric"]["clips"] == 16          # both ranks' micro-batches went through the one all-reduce
+
+
+def test_bench_rejects_mismatched_world_before_touching_a_gpu():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)

@@ -68,7 +68,9 @@ def main():
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev if backend == "nccl" else None)
     # every rank must hold the same parameters after the same steps (same init, summed gradients)
-    chk = torch.stack([o.param.double().sum() for o in opts.values()]).cpu()
+    chk = torch.stack([o.param.double().sum() for o in opts.values()])
+    if backend != "nccl":
+        chk = chk.cpu()          # gloo reduces host tensors; RCCL needs the tensor on this rank's GPU
     same = True
     if world > 1:
         lo, hi = chk.clone(), chk.clone()
