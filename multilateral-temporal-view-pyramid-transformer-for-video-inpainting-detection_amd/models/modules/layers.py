@@ -74,9 +74,3 @@ class Derived:
                 self._val = fn()
             self._key = key
         return self._val
-
-
-def train_guard(module: nn.Module):
-    if module.training and torch.is_grad_enabled():
-        # forward-only kernels: outputs carry no autograd graph.  Eval/no_grad use (test.py) is the supported path.
-        pass

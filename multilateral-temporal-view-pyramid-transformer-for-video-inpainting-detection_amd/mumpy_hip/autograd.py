@@ -504,8 +504,12 @@ def cross_swin_block_train(blk, x1, x2):
         hs2 = x2.shape[1] // w
         x1w = _windows(x1, hs1, w).contiguous()
         x2w = LinearFn.apply(_windows(x2, hs2, w).contiguous(), blk.pre.weight, blk.pre.bias)
-        yw = AddFn.apply(x1w, swin_dattention_train(blk.cva.crossattn, x1w, x2w))          # CVAModule: x1 + D (mTVE:138)
-        x1 = AddFn.apply(x1, yw.reshape(b, l1, c1))                       # window-major y added to raster x1 (mTVE:285-286)
+        # stochastic depth applies twice on this branch, as in the reference: CVAModule drops D per WINDOW (its input's
+        # leading axis is B*nW, mTVE:138), the block drops the window-major y per clip (mTVE:286); rates dpr[2,4,22] of
+        # stages 1-3 are non-zero (mTVE:553)
+        d = drop_path_train(blk.cva.drop_path, swin_dattention_train(blk.cva.crossattn, x1w, x2w))
+        yw = AddFn.apply(x1w, d)                                          # CVAModule: x1 + drop_path(D) (mTVE:138)
+        x1 = AddFn.apply(x1, drop_path_train(blk.drop_path, yw.reshape(b, l1, c1)))       # window-major y added to raster x1 (mTVE:285-286)
     z = LayerNormFn.apply(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
     return AddFn.apply(x1, drop_path_train(blk.drop_path, LinearFn.apply(hmid, blk.mlp.fc2.weight, blk.mlp.fc2.bias))), out

@@ -1,11 +1,16 @@
 """Checkpoint I/O in the reference's on-disk format and the clip index rule of the data loader (8f-4).
 
 Format (utils/utils.py:264-276): `encoder_{epoch}.pt` / `decoder_{epoch}.pt` (or `encoder.pt` / `decoder.pt`) are plain
-`state_dict`s written with `torch.save`; a model trained under `nn.DataParallel` carries a `module.` prefix on every key,
-which `check_parallel` strips (utils/utils.py:156-176).  Differences on purpose:
+`state_dict`s written with `torch.save`, `enc_opt_{epoch}.pt` / `dec_opt_{epoch}.pt` the optimizers' `state_dict`s
+(torch.optim.AdamW layout: `mumpy_hip.train.FlatAdamW.state_dict`); a model trained under `nn.DataParallel` carries a
+`module.` prefix on every key, which `check_parallel` strips (utils/utils.py:156-176).  The reference keeps a third
+optimizer for the cross-view parameters (train.py:211-213) that its own save_checkpoint drops; here it is written too
+(`cva_opt_{epoch}.pt`) so that a resumed run continues the same trajectory.  Differences on purpose:
   * files are read with `torch.load(..., weights_only=True)` only — nothing in a checkpoint is executed;
-  * the reference's `args.pkl` (a pickled argparse namespace, utils/utils.py:276,319) is never read; run arguments
-    travel as a JSON sidecar (`args.json`) instead.
+  * the reference's `args.pkl` (a pickled argparse namespace, utils/utils.py:276,319) is never read or written; run
+    arguments travel as a JSON sidecar (`args.json`).  Consequence: the reference's own `load_checkpoint`, which
+    unpickles `args.pkl` unconditionally (utils/utils.py:319), needs that one file supplied by the user to open a
+    directory written here; the four `.pt` files it reads are in its format.
 """
 import json
 import os
@@ -31,16 +36,34 @@ def _names(epoch: Optional[int]) -> Tuple[str, str]:
     return (f"encoder_{epoch}.pt", f"decoder_{epoch}.pt") if epoch is not None else ("encoder.pt", "decoder.pt")
 
 
+def _opt_name(key: str, epoch: Optional[int]) -> str:
+    return f"{key}_opt_{epoch}.pt" if epoch is not None else f"{key}_opt.pt"
+
+
 def save_checkpoint(directory: str, encoder: torch.nn.Module, decoder: torch.nn.Module, epoch: Optional[int] = None,
-                    args: Optional[dict] = None) -> None:
-    """utils/utils.py:264-276 minus the optimizer states (forward-only product) and with JSON instead of pickle."""
+                    args: Optional[dict] = None, optimizers: Optional[dict] = None) -> None:
+    """utils/utils.py:264-276 with JSON instead of pickle.  `optimizers`: the dict of mumpy_hip.train.build_optimizers
+    ({"enc", "dec"[, "cva"]}) -> enc_opt / dec_opt / cva_opt files."""
     os.makedirs(directory, exist_ok=True)
     en, dn = _names(epoch)
     torch.save(encoder.state_dict(), os.path.join(directory, en))
     torch.save(decoder.state_dict(), os.path.join(directory, dn))
+    for key, opt in (optimizers or {}).items():
+        torch.save(opt.state_dict(), os.path.join(directory, _opt_name(key, epoch)))
     if args is not None:
         with open(os.path.join(directory, "args.json"), "w") as f:
             json.dump(args, f, indent=1, sort_keys=True)
+
+
+def load_optimizer_states(directory: str, epoch: Optional[int] = None, map_location="cpu") -> Dict[str, dict]:
+    """{"enc": state_dict, "dec": ..., "cva": ...} for the optimizer files present (weights-only load: tensors, numbers,
+    lists and dicts only).  Feed each to FlatAdamW.load_state_dict to resume (train.py:179-188 does this with torch's)."""
+    out = {}
+    for key in ("enc", "dec", "cva"):
+        path = os.path.join(directory, _opt_name(key, epoch))
+        if os.path.exists(path):
+            out[key] = torch.load(path, map_location=map_location, weights_only=True)
+    return out
 
 
 def load_checkpoint(directory: str, epoch: Optional[int] = None, map_location="cpu") -> Tuple[dict, dict, Optional[dict]]:

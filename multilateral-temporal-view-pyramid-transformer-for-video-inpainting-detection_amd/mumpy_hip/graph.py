@@ -10,16 +10,32 @@ class GraphedForward:
         of test.py:100-108 coming out of the same last kernel."""
         self.encoder, self.decoder, self.with_mask = encoder, decoder, with_mask
         self.static_x = example.clone()
-        side = torch.cuda.Stream(device=example.device)
+        self._warmup = warmup
+        # load_state_dict rewrites parameters through torch (tensor versions move, the epoch does not): count it as a
+        # weights change too, so that a graph captured before it is re-captured
+        from .state import bump_weights_epoch
+        for m in (encoder, decoder):
+            m.register_load_state_dict_post_hook(lambda module, incompatible: bump_weights_epoch())
+        self._capture()
+
+    def _capture(self):
+        """The graph bakes in the addresses of the weights AND of the tensors derived from them (transposed tokenizer
+        weights, padded relative-position bias, concatenated k|v weights, KRSC convolution images -- models.modules.layers
+        .Derived).  An optimizer step or load_state_dict makes the eager path rebuild those; replaying an old graph would
+        then read freed or recycled memory.  So the capture remembers the weights epoch and __call__ re-captures when it
+        has moved (validation between training epochs keeps working; steady-state inference never pays for it)."""
+        from . import state
+        side = torch.cuda.Stream(device=self.static_x.device)
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():          # warm derived-table caches / MIOpen off the graph
-            for _ in range(warmup):
+        with torch.cuda.stream(side), torch.no_grad():          # warm the derived-table caches off the graph
+            for _ in range(self._warmup):
                 self._fwd()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = self._fwd()
+        self.weights_epoch = state.weights_epoch[0]
 
     def _fwd(self):
         from .pipeline import fused_forward
@@ -27,6 +43,9 @@ class GraphedForward:
 
     def __call__(self, x: torch.Tensor):
         """Returns the static (logits, feats) buffers; contents are overwritten by the next call."""
+        from . import state
+        if state.weights_epoch[0] != self.weights_epoch:           # weights (hence derived tensors) changed since capture
+            self._capture()
         self.static_x.copy_(x, non_blocking=True)
         self.graph.replay()
         return self.static_out

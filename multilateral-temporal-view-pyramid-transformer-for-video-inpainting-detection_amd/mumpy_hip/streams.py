@@ -15,8 +15,9 @@ _DEPTH = [0]            # nesting depth of run_parallel on this (host) thread: n
 SERIAL = os.environ.get("MUMPY_SERIAL", "0") == "1"
 
 
-def _side_stream(device, i):
-    key = (str(device), _DEPTH[0], i)
+def _side_stream(device, i, parent=None):
+    # keyed by the PARENT stream as well: two forks at the same depth under different parents never share a side stream
+    key = (str(device), _DEPTH[0], i, None if parent is None else parent.cuda_stream)
     if key not in _SIDE:
         prio = int(os.environ.get("MUMPY_SIDE_PRIORITY", "0"))      # (high priority measured slightly slower)
         _SIDE[key] = torch.cuda.Stream(device=device, priority=prio)
@@ -37,12 +38,19 @@ def run_parallel(branches, inputs):
     if SERIAL or len(branches) == 1:
         return [fn() for fn in branches]
     main = torch.cuda.current_stream()
+    # Forks are rooted on the stream the caller entered with, never on one of this module's side streams: a fork from a
+    # side stream inside hipGraph capture segfaulted in CUDAGraph.capture_end (ROCm 7.2; gpurun_out/crash.log of round 1:
+    # the nested fork's streams joined their side-stream parent, which itself joined the capturing stream only later).
+    # A nested fork reached on a side stream therefore runs its branches in order on that stream -- same kernels, same
+    # results; the rule is enforced here instead of by the order in which callers list their branches.
+    if any(main.cuda_stream == s.cuda_stream for s in _SIDE.values()):
+        return [fn() for fn in branches]
     fork = torch.cuda.Event()
     fork.record(main)
     outs = [None] * len(branches)
     sides = []
     for i in range(len(branches) - 1):
-        sides.append(_side_stream(main.device, i))     # streams of THIS depth
+        sides.append(_side_stream(main.device, i, main))     # streams of THIS depth and parent
     _DEPTH[0] += 1
     try:
         for i, fn in enumerate(branches[:-1]):

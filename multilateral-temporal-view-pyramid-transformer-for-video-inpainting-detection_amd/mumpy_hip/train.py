@@ -76,6 +76,43 @@ class FlatAdamW:
     def zero_grad(self):
         self.grad.zero_()
 
+    # ---- checkpointing: torch.optim.AdamW's state_dict layout, so a file written here reads like the reference's
+    # enc_opt_{e}.pt / dec_opt_{e}.pt (utils/utils.py:264-276) and vice versa; the counters torch keeps elsewhere
+    # (scheduler position, base rate) ride in an extra "mumpy" entry that torch's loader ignores
+    def state_dict(self) -> dict:
+        state = {}
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + n].view_as(p).detach().clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).detach().clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "params": list(range(len(self.params)))}
+        return {"state": state, "param_groups": [group], "mumpy": {"steps": self.steps, "sched_it": self.sched_it, "base_lr": self.base_lr}}
+
+    def load_state_dict(self, sd: dict) -> None:
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.params):
+            raise ValueError(f"FlatAdamW.load_state_dict: expected one group of {len(self.params)} parameters")
+        g = groups[0]
+        self.lr, self.betas, self.eps, self.weight_decay = float(g["lr"]), tuple(g["betas"]), float(g["eps"]), float(g["weight_decay"])
+        steps = 0
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            n = p.numel()
+            if st is None:                                   # torch omits parameters that never received a gradient
+                self.exp_avg[o:o + n].zero_(); self.exp_avg_sq[o:o + n].zero_()
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"FlatAdamW.load_state_dict: parameter {i} has shape {tuple(p.shape)}, state {tuple(st['exp_avg'].shape)}")
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps = max(steps, int(float(st["step"])))
+        extra = sd.get("mumpy", {})
+        self.steps = int(extra.get("steps", steps))          # (one step count per group: every parameter steps together here)
+        self.sched_it = int(extra.get("sched_it", self.steps))
+        self.base_lr = float(extra.get("base_lr", g.get("initial_lr", self.lr)))
+
     def all_reduce_grads(self, bucket_bytes: int = 64 << 20):
         """Sum all-reduce of the flat gradient in buckets (RCCL ring over xGMI: per-link bound, so a few tens of MB per
         call keeps the ring busy without delaying the first bucket); returns the factor AdamW must apply (1/world)."""

@@ -748,6 +748,39 @@ def test_hip_graph_replay_is_identical(model_t3):
         assert torch.equal(g(x)[0], eager)
 
 
+def test_nested_fork_in_a_side_branch_is_capturable():
+    """A fork reached on one of streams.py's side streams (a nested fork in a NON-last branch) runs its branches in order
+    on that stream -- the schedule that segfaulted CUDAGraph.capture_end in round 1 (gpurun_out/crash.log) can no longer
+    be built.  Captured and replayed here; results equal the serial order."""
+    from mumpy_hip import ops, streams
+    x = torch.randn(512, 256, device=DEV)
+    w = [torch.randn(256, 256, device=DEV) / 16 for _ in range(4)]
+
+    def inner(t):
+        a, b = streams.run_parallel([lambda: ops.linear(t, w[0]), lambda: ops.linear(t, w[1])], [(t,), (t,)])
+        return ops.add(a, b)
+
+    def fwd():
+        # the FIRST branch goes to a side stream and forks again there
+        p, q = streams.run_parallel([lambda: inner(x), lambda: ops.linear(inner(x), w[2])], [(x,), (x,)])
+        return ops.add(p, q)
+
+    with torch.no_grad():
+        ref = fwd().clone()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fwd()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.cuda.graph(g):
+            out = fwd()
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
 def test_fused_pipeline_matches_sequential_calls(model_t3):
     """mumpy_hip.pipeline.fused_forward (global blocks || decoder branches) == Decoder()(*Encoder()(x)), bit for bit."""
     from mumpy_hip.pipeline import fused_forward
@@ -775,3 +808,23 @@ def test_encoder_graph_replay_bit_exact(model_t3):
     torch.cuda.synchronize()
     assert torch.equal(gfx, fx) and torch.equal(gdx, dx)
     assert all(torch.equal(a, b) for sa, sb in zip(gvx, vx) for a, b in zip(sa, sb))
+
+
+def test_graphed_forward_recaptures_after_a_weight_change(model_t3):
+    """A GraphedForward captured before the weights change (optimizer step, load_state_dict) must not replay against the
+    stale weight-derived tensors its launches point at: it re-captures and matches the eager forward of the new weights."""
+    from mumpy_hip.graph import GraphedForward
+    enc, dec = model_t3
+    x = seeded_randn(91, 1, 3, 3, 224, 224).to(DEV)
+    g = GraphedForward(enc, dec, x)
+    before = g(x)[0].clone()
+    sd = {k: v.clone() for k, v in dec.state_dict().items()}
+    try:
+        sd2 = {k: (v * 1.25 if k.endswith("final_out.weight") else v) for k, v in sd.items()}
+        dec.load_state_dict(sd2, strict=True)
+        with torch.no_grad():
+            eager = dec(*enc(x))[0].clone()
+        after = g(x)[0]
+        assert torch.equal(after, eager) and not torch.equal(after, before)
+    finally:
+        dec.load_state_dict(sd, strict=True)

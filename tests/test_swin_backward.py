@@ -296,6 +296,66 @@ def test_hip_drop_path_train_mode():
 
 
 @pytest.mark.gpu
+def test_hip_cross_block_drop_path_train_mode():
+    """Train-mode parity of the cross-view branch (mTVE:138, 286): CVAModule drops the deformable output per WINDOW, the
+    block then drops the window-major sum per clip.  (i) block rate ~1: all three residual branches vanish, x1 comes back
+    unchanged (without the second wrap x1 + y would survive); (ii) CVA rate ~1, block rate 0: the result equals the eval
+    forward of the same block with a zeroed deformable branch; (iii) the masks are drawn per window / per clip, in the
+    reference's order, from torch's generator."""
+    from models.encoder.multiTemporalViewEncoder import CrossSwinBlock
+    from models.modules.layers import DropPath
+    from mumpy_hip.autograd import cross_swin_block_train
+    blk = fill_module_(CrossSwinBlock(96, 128, (14, 14), 3, temporal_dims=1, drop_path=0.5), "csb/").cuda()
+    assert isinstance(blk.drop_path, DropPath) and isinstance(blk.cva.drop_path, DropPath)
+    x1, x2 = seeded_randn(50, 4, 196, 96).cuda(), seeded_randn(51, 4, 196, 128).cuda()
+    blk.eval()
+    with torch.no_grad():
+        y_eval, out_eval = cross_swin_block_train(blk, x1, x2)
+    blk.train()
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.999999, 0.0
+    torch.manual_seed(2)
+    with torch.no_grad():
+        y, out = cross_swin_block_train(blk, x1, x2)
+    assert torch.equal(y, x1) and torch.equal(out, out_eval)                    # (i)
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.0, 0.999999
+    torch.manual_seed(2)
+    with torch.no_grad():
+        y = cross_swin_block_train(blk, x1, x2)[0]
+    blk.eval()
+    saved = (blk.cva.crossattn.proj_out.weight.detach().clone(), blk.cva.crossattn.proj_out.bias.detach().clone())
+    with torch.no_grad():
+        blk.cva.crossattn.proj_out.weight.zero_(); blk.cva.crossattn.proj_out.bias.zero_()
+        from mumpy_hip.state import bump_weights_epoch
+        bump_weights_epoch()
+        y_nod = cross_swin_block_train(blk, x1, x2)[0]
+        blk.cva.crossattn.proj_out.weight.copy_(saved[0]); blk.cva.crossattn.proj_out.bias.copy_(saved[1])
+        bump_weights_epoch()
+    assert rel_err(y.cpu(), y_nod.cpu()) < 1e-6 and rel_err(y.cpu(), y_eval.cpu()) > 1e-3      # (ii)
+    # (iii) draw order and mask shapes: block [B] on the W-MSA output, CVA [B*nW] on D, block [B] on y, block [B] on the MLP
+    blk.train()
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.5, 0.5
+    calls = []
+    import mumpy_hip.autograd as A
+    orig = A.DropPathFn.apply
+
+    def spy(x, scale):
+        calls.append((tuple(x.shape), scale.clone()))
+        return orig(x, scale)
+    A.DropPathFn.apply = spy
+    try:
+        torch.manual_seed(3)
+        with torch.no_grad():
+            cross_swin_block_train(blk, x1, x2)
+    finally:
+        A.DropPathFn.apply = orig
+    assert [c[0] for c in calls] == [(4, 196, 96), (16, 49, 96), (4, 196, 96), (4, 196, 96)]
+    torch.manual_seed(3)
+    for shape, scale in calls:                       # the same stream of Bernoulli(keep)/keep draws timm's drop_path makes
+        ref = torch.empty(shape[0], device="cuda").bernoulli_(0.5).div_(0.5)
+        assert torch.equal(scale, ref)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("t", [1, 3, 5, 16])
 def test_hip_global_block_backward_vs_oracle(t):
     """Global temporal ViT block (row 13): output, input gradient and every parameter gradient against autograd on the

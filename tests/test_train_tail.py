@@ -192,6 +192,73 @@ def test_flat_adamw_trains_like_torch_adamw():
         assert rel_err(a.detach().cpu(), b.detach().cpu()) < 1e-5
 
 
+def test_flat_adamw_state_dict_is_torch_adamw_layout(tmp_path):
+    """CPU: FlatAdamW.state_dict() has torch.optim.AdamW's layout (the reference's enc_opt / dec_opt files,
+    utils/utils.py:266-271): torch's own AdamW loads it, and a file torch wrote loads back -- through the weights-only
+    loader of mumpy_hip.checkpoint."""
+    from mumpy_hip import checkpoint as C
+    from mumpy_hip.train import FlatAdamW
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2))
+    opt = FlatAdamW(net.parameters(), lr=2e-3, weight_decay=1e-3)
+    opt.exp_avg.normal_(); opt.exp_avg_sq.uniform_(); opt.steps, opt.sched_it, opt.lr = 11, 9, 1.5e-3
+    enc = torch.nn.Linear(2, 2)
+    C.save_checkpoint(str(tmp_path), enc, enc, epoch=3, optimizers={"enc": opt, "dec": opt, "cva": opt})
+    for f in ("enc_opt_3.pt", "dec_opt_3.pt", "cva_opt_3.pt", "encoder_3.pt", "decoder_3.pt"):
+        assert (tmp_path / f).exists()
+    sds = C.load_optimizer_states(str(tmp_path), epoch=3)
+    assert set(sds) == {"enc", "dec", "cva"}
+    twin = torch.optim.AdamW(net.parameters(), lr=1.0)
+    twin.load_state_dict({k: v for k, v in sds["enc"].items() if k != "mumpy"})             # torch accepts it as its own
+    assert twin.param_groups[0]["lr"] == 1.5e-3 and twin.param_groups[0]["weight_decay"] == 1e-3
+    for i, p in enumerate(net.parameters()):
+        o = opt.offsets[i]
+        assert torch.equal(twin.state[p]["exp_avg"].reshape(-1), opt.exp_avg[o:o + p.numel()])
+        assert float(twin.state[p]["step"]) == 11.0
+    fresh = FlatAdamW(torch.nn.Sequential(torch.nn.Linear(6, 4), torch.nn.Linear(4, 2)).parameters(), lr=9.0)
+    fresh.load_state_dict(twin.state_dict())                                                # and back, from torch's own dict
+    for i in range(len(opt.params)):                 # (the flat buffers' alignment padding between parameters is not state)
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(fresh.state_dict()["state"][i][k], opt.state_dict()["state"][i][k])
+    assert (fresh.steps, fresh.lr, fresh.weight_decay) == (11, 1.5e-3, 1e-3)
+    fresh.load_state_dict(sds["enc"])
+    assert (fresh.steps, fresh.sched_it, fresh.base_lr) == (11, 9, 2e-3)
+
+
+@pytest.mark.gpu
+def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
+    """save -> load -> continue == never having stopped: parameters, both moments, step and scheduler counters survive
+    (train.py:179-188 resumes encoder, decoder and both optimizers)."""
+    from mumpy_hip import checkpoint as C
+    from mumpy_hip.train import FlatAdamW
+
+    def make():
+        torch.manual_seed(8)
+        return torch.nn.Sequential(torch.nn.Linear(9, 8), torch.nn.GELU(), torch.nn.Linear(8, 4)).cuda()
+
+    x = seeded_randn(6, 32, 9).cuda()
+
+    def run(net, opt, n):
+        for _ in range(n):
+            net(x).square().mean().backward()
+            opt.step()
+            opt.zero_grad()
+            opt.scheduler_step(iter_max=20)
+
+    a = make(); oa = FlatAdamW(a.parameters(), lr=1e-2, weight_decay=1e-3)
+    run(a, oa, 10)                                                        # the uninterrupted run
+    b = make(); ob = FlatAdamW(b.parameters(), lr=1e-2, weight_decay=1e-3)
+    run(b, ob, 4)
+    C.save_checkpoint(str(tmp_path), b, b, epoch=0, optimizers={"enc": ob})
+    c = make(); oc = FlatAdamW(c.parameters(), lr=123.0)                  # a fresh process: wrong rate, zero moments
+    e, _, _ = C.load_checkpoint(str(tmp_path), epoch=0)
+    c.load_state_dict(e, strict=True)
+    oc.load_state_dict(C.load_optimizer_states(str(tmp_path), epoch=0)["enc"])
+    run(c, oc, 6)
+    assert torch.equal(oc.param, oa.param) and torch.equal(oc.exp_avg, oa.exp_avg) and torch.equal(oc.exp_avg_sq, oa.exp_avg_sq)
+    assert (oc.steps, oc.sched_it, oc.lr) == (oa.steps, oa.sched_it, oa.lr)
+
+
 def _ddp_worker(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     from conftest import PKG  # noqa: F401
