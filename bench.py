@@ -187,7 +187,17 @@ def cpu_baseline(frames, sample_b):
             ts.append(time.perf_counter() - t0)
             log(f"  B={sample_b} pass: {ts[-1]:.2f} s")
     t = min(ts)
-    return {"value": round(sample_b / t, 3), "unit": "clips/s", "cores": cores, "kind": "port",
+    # how the oracle compares with the reference's own CPU forward (measured where both can run: the build container,
+    # tools/cpu_ref_ratio.py -> tests/golden/cpu_ref_ratio.json; the round-1 review measured 1.50 vs 0.98 clips/s there)
+    ratio = None
+    try:
+        r = json.load(open(os.path.join(ROOT, "tests", "golden", "cpu_ref_ratio.json")))
+        ratio = {"oracle_over_reference": r["oracle_over_reference"], "oracle_clips_s": r["oracle_clips_s"],
+                 "reference_clips_s": r["reference_clips_s"], "where": "build container, 8 vCPU (tools/cpu_ref_ratio.py)",
+                 "reference_equivalent_value": round(sample_b / t / r["oracle_over_reference"], 3)}
+    except (OSError, KeyError):
+        pass
+    return {"value": round(sample_b / t, 3), "unit": "clips/s", "cores": cores, "kind": "port", "ref_ratio": ratio,
             "sample": f"oracle full forward, B={sample_b}, T={frames}, 224x224 fp32, 1 warm-up (B=1) + 3 timed, best of 3 "
                       f"({t:.2f} s per pass)"}
 
@@ -333,10 +343,10 @@ def main():
         # WRITE_SIZE; tools/pmc_bench.sh + tools/summarize_pmc_bench.py -> profiles/): bench.py cannot run rocprofv3 on itself
         dom["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_bench_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
             if args.math == "fp32" and args.batch == 8 and args.frames == 5 and dom["kernel"] in pmc:
                 dom["traffic"] = pmc[dom["kernel"]]["hbm_bytes_per_launch"]
-                dom["traffic_unit"] = "B per launch (PMC: profiles/r01_pmc_bench_traffic.md)"
+                dom["traffic_unit"] = "B per launch (PMC: profiles/r02_pmc_bench_traffic.md)"
         except OSError:
             pass
         dom.pop("launches", None)

@@ -471,6 +471,50 @@ def test_full_model_b16_t5_vs_oracle():
     assert rel_err(fx.cpu(), ref[2]) < TOL
 
 
+def test_full_model_b8_t5_vs_oracle_every_view_tensor():
+    """EXACTLY the benchmark configuration (BASELINE configs[1]: B=8, T=5, 224x224, fp32), HIP vs oracle on the host:
+    mask logits, final features and all twelve per-stage view tensors element by element (not digests), with the error
+    normalised per tensor by its RMS as well as by its maximum."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = seeded_randn(858, 8, 5, 3, 224, 224)
+    with torch.no_grad():
+        fx, vx, dx = enc(x.to(DEV))
+        logits, _ = dec(fx, vx, dx)
+        ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)
+
+    def rms_err(a, b):
+        a, b = a.double(), torch.as_tensor(b).double()
+        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
+    assert rel_err(logits.cpu(), ref[0]) < TOL and rms_err(logits.cpu(), ref[0]) < TOL
+    assert rel_err(fx.cpu(), ref[2]) < TOL and rms_err(fx.cpu(), ref[2]) < TOL
+    ref_views = ref[3]
+    for s in range(4):
+        for v in range(3):
+            got, want = vx[s][v].cpu(), ref_views[s][v]
+            assert got.shape == want.shape
+            assert rel_err(got, want) < TOL and rms_err(got, want) < TOL, (s, v)
+
+
+def test_full_model_b8_t9_vs_oracle():
+    """Config 4's batch and clip length (B=8, T=9, tubelets (9,8,1)) at the resolution the reference feeds the network
+    (224x224 after its loader's resize): view 3 has 8 x 9 x 3136 = 225,792 rows in stage 0 -- index widths, grid limits,
+    the r = 9 window aggregation of the deformable attention and the persistent GEMM's tile counts at that size."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=9), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 9]), DEV)
+    x = seeded_randn(8989, 8, 9, 3, 224, 224)
+    with torch.no_grad():
+        fx, vx, dx = enc(x.to(DEV))
+        logits, _ = dec(fx, vx, dx)
+        ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)
+    assert rel_err(logits.cpu(), ref[0]) < TOL
+    assert rel_err(fx.cpu(), ref[2]) < TOL
+
+
 def test_baseline_encoder(full_golden):
     from models.encoder.encoder import BaselineEncoder
     enc = _load_filled(BaselineEncoder(), DEV)
