@@ -204,9 +204,12 @@ __device__ __forceinline__ const f32x4* at16(const char* base, uint32_t off) {
     return reinterpret_cast<const f32x4*>(base + off);
 }
 
+// DBG = false is the shipped instantiation: the MUMPY_WA_DBG ablation switches (skip loads / MFMAs / stores) exist only in
+// the diagnostic instantiation, which the launcher selects when that variable is set.
+template <bool DBG>
 __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     __shared__ uint32_t tok_in[4][64];    // token * (3C*4): byte offset of the token's qkv row
-    __shared__ uint32_t tok_out[4][64];   // token * (C*4):  byte offset of the token's out row
+    __shared__ __attribute__((aligned(16))) uint32_t tok_out[4][64];   // token * (C*4):  byte offset of the token's out row
     __shared__ __attribute__((aligned(16))) float bias_s[WT * BLD];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -245,7 +248,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     // q/k/v go straight to registers (MFMA operand layout); branch-free
     f32x4 qf[2][4], kf[2][4];
     float vf[2][16];
-    if (!(a.dbg & 1)) {
+    const int dbg = DBG ? a.dbg : 0;
+    if (!(dbg & 1)) {
         const char* kbase = base + 4 * a.C;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -286,11 +290,11 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
             for (int jt = 0; jt < 2; ++jt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[jt][r] = 0.f;
-            if (!(a.dbg & 2)) qk_product(s, kf, qf[it]);
+            if (!(dbg & 2)) qk_product(s, kf, qf[it]);
             else { s[0][0] = kf[0][0][0] + qf[it][0][0]; s[1][3] = kf[1][1][1] * qf[it][2][1]; }
             const int qi = 32 * it + c;
             const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];    // padded queries re-read row 48
-            if (!(a.dbg & 2))
+            if (!(dbg & 2))
                 bias_softmax<MASKED>(s, [&](int jt, int g) {
                     f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
                     if (jt == 1 && g == 2 && h) bv.x = -1e30f;                     // key 52 is padding (key 48 is real)
@@ -299,14 +303,20 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
             f32x16 o;
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[r] = 0.f;
-            if (!(a.dbg & 2)) pv_product(o, s, vf);
+            if (!(dbg & 2)) pv_product(o, s, vf);
             else { o[0] = s[0][0] + vf[0][0]; o[5] = s[1][2] * vf[1][8]; }
-            if (!(a.dbg & 4)) {
+            if (!(dbg & 4)) {
+                // row offsets of the 4 consecutive queries a lane's register group g holds: one 16-byte table read
+                typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+                u32x4v to4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    if (!(it == 1 && g == 3)) to4[g] = *reinterpret_cast<const u32x4v*>(&to[32 * it + 8 * g + 4 * h]);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
                     const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (i < WT) *reinterpret_cast<float*>(obase + (to[i] + 4u * c)) = o[r];
+                    if (i < WT) *reinterpret_cast<float*>(obase + (to4[r >> 2][r & 3] + 4u * c)) = o[r];
                 }
             } else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1;
         }
@@ -892,7 +902,8 @@ extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const fl
     if (groups > quads) groups = quads;
     a.groups = (int)groups; a.stagger = wa_stagger;
     const int64_t grid = groups * a.nH;
-    hipLaunchKernelGGL(win_attn_self_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    if (dbgmask) hipLaunchKernelGGL(win_attn_self_kernel<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(win_attn_self_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention");
     return 0;
 }
