@@ -401,6 +401,35 @@ def main():
                     out["alt_" + mode] = {"error": repr(e)[:200]}
                 finally:
                     ops.set_matrix_math("fp32")
+        if args.math == "fp32" and world == 1 and not args.no_alt:
+            # BASELINE config 3's per-GPU workload as written: bf16 STORAGE inside the Swin blocks (LayerNorm output, qkv,
+            # attention output and the 4C MLP hidden tensor are bf16 in HBM, weights read as bf16) + bf16 matrix math for every
+            # other GEMM / convolution; fp32 accumulate, statistics and residual stream (test_full_model_bf16_storage_b8_t5)
+            try:
+                log("alt: bf16 storage")
+                ops.set_storage("bf16")
+                with torch.no_grad():
+                    fused_forward(enc, dec, x, with_mask=True)
+                fwd16 = None if args.no_graph else GraphedForward(enc, dec, x, with_mask=True)
+                run16 = (lambda: fused_forward(enc, dec, x, with_mask=True)[1]) if fwd16 is None else (lambda: fwd16(x)[1])
+                for _ in range(2):
+                    run16()
+                torch.cuda.synchronize()
+                t3 = time.perf_counter()
+                for _ in range(args.steps):
+                    mask16 = run16()
+                torch.cuda.synchronize()
+                dt3 = time.perf_counter() - t3
+                out["alt_bf16_storage"] = {"what": "config 3 arithmetic and storage: bf16 activations/weights in HBM inside the Swin blocks, "
+                                                   "bf16 MFMA products everywhere, f32 accumulate / statistics / residual stream",
+                                           "value": round(args.batch * args.steps / dt3, 3), "unit": "clips/s",
+                                           "ms_per_step": round(1e3 * dt3 / args.steps, 3),
+                                           "mask_pixels_differing_from_fp32_path": int((mask16 != mask).sum())}
+                del fwd16
+            except Exception as e:
+                out["alt_bf16_storage"] = {"error": repr(e)[:200]}
+            finally:
+                ops.set_storage("fp32")
         if not args.no_cpu_baseline and world == 1:
             log("cpu baseline (oracle on host cores)")
             try:

@@ -58,6 +58,10 @@ const char* mumpy_last_error(void);
 int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,
                         int64_t rows, int C, float eps, void* stream);
 
+/* Same with y written as bf16 (config 3's activation storage; statistics and arithmetic stay fp32). */
+int mumpy_layernorm_bf16_fwd(const float* x, const float* gamma, const float* beta, void* y,
+                             int64_t rows, int C, float eps, void* stream);
+
 /* ---- Linear: y = act(x @ W^T + bias) + residual   — nn.Linear at swin:142,164,46-49; blocks:57-71,27-33;
  *      1x1 convs of deform:333,361,362,402; mTVE:283 (pre), mTVE:740 (globalembedding); swin:365 (reduction).
  * x (M,K), W (N,K) [nn.Linear weight layout], bias (N) or NULL, residual (M,N) or NULL, y (M,N).
@@ -72,6 +76,13 @@ int mumpy_linear_fwd(const float* x, const float* W, const float* bias, const fl
 int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
                         int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* bf16 STORAGE (BASELINE config 3 as written: bf16 weights and activations in HBM, fp32 accumulate): x (M,K) and W (N,K) are
+ * bf16 (the caller keeps bf16 copies of the nn.Linear weights), bias and residual fp32, y bf16 (out_bf16 != 0) or fp32 (the
+ * residual stream stays fp32).  Products on v_mfma_f32_32x32x16_bf16; no split-K.  The reference has no bf16 path: the
+ * tolerance against its fp32 forward is build-defined (2e-2 relative on the logits). */
+int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float* bias, const float* residual, void* y,
+                           int64_t M, int N, int K, int act, int out_bf16, void* stream);
 
 /* Same, with the rows of x grouped in blocks: row m lives at x + (m / rows_per_block) * block_stride +
  * (m % rows_per_block) * K (floats).  Feeds one time slice of the (B, T*n, C) view-3 tokens to the decoder's
@@ -107,6 +118,11 @@ int mumpy_conv2d_nhwc_fwd(const float* x, const float* w_krsc, const float* bias
 int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
                                const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
                                float scale, void* stream);
+
+/* Same with qkv and out stored as bf16 (bias / mask tables fp32, fp32 arithmetic). */
+int mumpy_window_attention_bf16_fwd(const void* qkv, void* out, const float* bias, const float* mask_tab,
+                                    const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
+                                    float scale, void* stream);
 
 /* ---- Deformable cross-view attention (SwinDAttention, deform:324-405) — four kernels -------------- */
 

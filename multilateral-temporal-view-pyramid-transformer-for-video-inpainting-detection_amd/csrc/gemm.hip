@@ -71,7 +71,8 @@ __device__ __attribute__((aligned(128))) float g_zero_page[32];
 // lane part is computed once.  (The 64-bit m * N form costs two quarter-rate v_mul_lo_u32 and a v_mad_u64 per stored
 // row: 5-15 % of a short-K tile.)  ksplit > 1: raw partial sums -> slab[ks][M][N]; bias/act/residual happen in
 // splitk_reduce_kernel.
-template <int TM, int TN, int WM, int WN>
+// OUT16: y is bf16 (config 3's activation storage); bias / residual / partial slabs stay fp32.
+template <int TM, int TN, int WM, int WN, bool OUT16 = false>
 __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], int64_t m0, int n0, int wm, int wn, int c, int h,
                                            int64_t M, int N, const float* __restrict__ bias, const float* residual,
                                            float* Y, int act, int ksplit, int ks, float* slab) {
@@ -96,7 +97,7 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], int64_t 
         }
         return;
     }
-    char* Yw = reinterpret_cast<char*>(Y + wbase);
+    char* Yw = OUT16 ? reinterpret_cast<char*>(reinterpret_cast<__bf16*>(Y) + wbase) : reinterpret_cast<char*>(Y + wbase);
     const char* Rw = residual ? reinterpret_cast<const char*>(residual + wbase) : nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -113,7 +114,8 @@ __device__ __forceinline__ void store_tile(const f32x16 (&acc)[TM][TN], int64_t 
                 float v = acc[i][j][r] + bv;
                 if (act == MUMPY_ACT_GELU) v = gelu_erf(v);
                 if (Rw) v += *reinterpret_cast<const float*>(Rw + off);
-                *reinterpret_cast<float*>(Yw + off) = v;
+                if (OUT16) *reinterpret_cast<__bf16*>(Yw + (off >> 1)) = (__bf16)v;      // round to nearest even
+                else *reinterpret_cast<float*>(Yw + off) = v;
             }
     }
 }
@@ -409,7 +411,9 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int LDH = 20;
 
-template <int BM, int BN, int WM, int WN, bool CONV, int NP = 1, int NBUF = 2>
+// IN16: x and W are bf16 in memory (bf16 STORAGE, config 3 as written: the staging traffic halves and there is nothing to
+// convert); OUT16: y is written as bf16.  Both only with NP == 1 and dense rows.
+template <int BM, int BN, int WM, int WN, bool CONV, int NP = 1, int NBUF = 2, bool IN16 = false, bool OUT16 = false>
 __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __restrict__ X, const float* __restrict__ Wt,
                                                             const float* __restrict__ bias, const float* residual,
                                                             float* Y, int64_t M, int N, int K, int act, unsigned gn,
@@ -447,7 +451,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
     // conflict-free at this 20-dword pitch -- SQ_LDS_BANK_CONFLICT 8.1 M -> 1.8 M cycles per launch -- with no change in the
     // kernel's duration: the LDS is not what the waves wait on.)
     const int ld_row = tid >> 3, ld_c4 = tid & 7;
+    static_assert(!(IN16 || OUT16) || (NP == 1 && !CONV), "bf16 storage: plain bf16 products on dense operands only");
     f32x4 areg[A_LD], breg[B_LD];
+    uint2 areg16[IN16 ? A_LD : 1], breg16[IN16 ? B_LD : 1];      // IN16: 4 bf16 per lane per row pass, as they come
     const float* arow[A_LD];
     const float* brow[B_LD];
     int ayx[A_LD];
@@ -455,6 +461,11 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
     for (int i = 0; i < A_LD; ++i) {
         int64_t m = m0 + ld_row + RPI * i;
         if (m > M - 1) m = M - 1;
+        if (IN16) {                                                         // element offsets halve: arow counts in floats
+            ayx[i] = 0;
+            arow[i] = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(X) + m * K + 4 * ld_c4);
+            continue;
+        }
         if (CONV) {
             const unsigned mu = (unsigned)m, qx = mu / (unsigned)cg.W;       // M < 2^31 (checked on the host): 32-bit division
             ayx[i] = ((int)(qx % (unsigned)cg.H) << 16) | (int)(mu - qx * (unsigned)cg.W);
@@ -472,9 +483,17 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
     for (int i = 0; i < B_LD; ++i) {
         int n = n0 + ld_row + RPI * i;
         if (n > N - 1) n = N - 1;
-        brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
+        if (IN16) brow[i] = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(Wt) + (int64_t)n * K + 4 * ld_c4);
+        else brow[i] = Wt + (int64_t)n * K + 4 * ld_c4;
     }
     auto gload = [&](int k0) {
+        if (IN16) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) areg16[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(arow[i]) + k0);
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) breg16[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const __bf16*>(brow[i]) + k0);
+            return;
+        }
         if (CONV) {
             const int tap = k0 / cg.Cin, c0 = k0 - tap * cg.Cin;
             const int dy = tap / cg.kw - cg.ph, dx = tap % cg.kw - cg.pw;
@@ -506,6 +525,13 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         }
     };
     auto lstore = [&](int buf) {
+        if (IN16) {
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) *reinterpret_cast<uint2*>(&lds[buf][(ld_row + RPI * i) * LDH + 2 * ld_c4]) = areg16[i];
+#pragma unroll
+            for (int i = 0; i < B_LD; ++i) *reinterpret_cast<uint2*>(&lds[buf][(BM + ld_row + RPI * i) * LDH + 2 * ld_c4]) = breg16[i];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) lstore_row(&lds[buf][(ld_row + RPI * i) * LDH + 2 * ld_c4], areg[i]);
 #pragma unroll
@@ -590,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
         fread(0);
         mma();
     }
-    store_tile<TM, TN, WM, WN>(acc, m0, n0, wm, wn, c, h, M, N, bias, residual, Y, act, ksplit, ks, slab);
+    store_tile<TM, TN, WM, WN, OUT16>(acc, m0, n0, wm, wn, c, h, M, N, bias, residual, Y, act, ksplit, ks, slab);
 }
 
 // split-K combine: y = act(sum_s slab[s] + bias) + residual, slices summed in fixed order (bitwise reproducible)
@@ -851,6 +877,41 @@ extern "C" int mumpy_linear_ws_fwd(const float* x, const float* W, const float* 
     MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "linear: workspace must be 16-byte aligned");
     return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream));
+}
+
+// bf16 STORAGE (config 3 as written): x (M,K) and W (N,K) bf16, bias / residual fp32, y bf16 (out_bf16 != 0) or fp32.
+extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float* bias, const float* residual, void* y,
+                                      int64_t M, int N, int K, int act, int out_bf16, void* stream) {
+    if (M == 0) return 0;
+    MUMPY_REQUIRE(x && W && y, MUMPY_ENULL, "linear_bf16s: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(W) && aligned16(y) && aligned16(residual), MUMPY_EALIGN,
+                  "linear_bf16s: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(M > 0 && M < (1ll << 31) - 256 && (int64_t)N * 4 * 128 < (1ll << 32), MUMPY_ERANGE, "linear_bf16s: M=%lld / N=%d out of range", (long long)M, N);
+    MUMPY_REQUIRE(N > 0 && K > 0 && K % BK == 0 && N % 32 == 0, MUMPY_EINVAL, "linear_bf16s: need K %% 32 == 0 and N %% 32 == 0 (got N=%d K=%d)", N, K);
+    MUMPY_REQUIRE(act == MUMPY_ACT_NONE || act == MUMPY_ACT_GELU, MUMPY_EINVAL, "linear_bf16s: unknown act %d", act);
+    const float* xf = static_cast<const float*>(x);
+    const float* wf = static_cast<const float*>(W);
+    float* yf = static_cast<float*>(y);
+    const ConvGeom cg{0, 0, 0, 0, 0, 0, 0};
+    hipStream_t s = as_stream(stream);
+    const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
+    const unsigned gn128 = (N + 127) / 128, gn64 = (N + 63) / 64;
+    // the products take 1/16 of the fp32 MFMA time: these launches are staging-bound, so prefer the wide tile (half the
+    // operand traffic per FLOP) as soon as it yields about a round of workgroups
+    const bool wide = gm128 * gn128 >= 200;
+    const unsigned gn = wide ? gn128 : gn64;
+    const int64_t grid = (wide ? gm128 : gm64) * gn;
+    MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear_bf16s: too many tiles");
+#define MUMPY_GEMM_S(BM_, BN_, WM_, WN_, O16_)                                                                             \
+    hipLaunchKernelGGL((linear_bf16_kernel<BM_, BN_, WM_, WN_, false, 1, 2, true, O16_>), dim3((unsigned)grid), dim3(256), 0, s, \
+                       xf, wf, bias, residual, yf, M, N, K, act, gn, 1, nullptr, M, (int64_t)0, cg)
+    if (wide && out_bf16) MUMPY_GEMM_S(128, 128, 64, 64, true);
+    else if (wide) MUMPY_GEMM_S(128, 128, 64, 64, false);
+    else if (out_bf16) MUMPY_GEMM_S(64, 64, 32, 32, true);
+    else MUMPY_GEMM_S(64, 64, 32, 32, false);
+#undef MUMPY_GEMM_S
+    MUMPY_CHECK_LAUNCH("linear_bf16s");
+    return 0;
 }
 
 extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, const float* W,

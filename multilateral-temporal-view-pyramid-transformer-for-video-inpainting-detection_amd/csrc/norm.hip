@@ -9,7 +9,8 @@ namespace {
 constexpr int MAXNV = 16;  // float4 per lane: C <= 64 lanes * 16 * 4 = 4096
 
 // SRC: functor giving the address of float4 index v (0..C/4) of virtual row `row`.
-template <typename SRC>
+// OUT16: y is bf16 (the activation storage of config 3); statistics and arithmetic stay fp32.
+template <typename SRC, bool OUT16 = false>
 __global__ __launch_bounds__(256) void ln_rows_kernel(SRC src, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, float* __restrict__ y,
                                                       int64_t rows, int C, int lpr, int nv, float eps) {
@@ -48,7 +49,13 @@ __global__ __launch_bounds__(256) void ln_rows_kernel(SRC src, const float* __re
             const int c4 = l + i * lpr;
             const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + 4 * c4);
             const f32x4 b = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
-            *reinterpret_cast<f32x4*>(yr + 4 * c4) = (v[i] - mean) * rstd * g + b;
+            const f32x4 o = (v[i] - mean) * rstd * g + b;
+            if (OUT16) {
+                typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+                *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(y) + row * (int64_t)C + 4 * c4) = __builtin_convertvector(o, bf16x4v);
+            } else {
+                *reinterpret_cast<f32x4*>(yr + 4 * c4) = o;
+            }
         }
     }
 }
@@ -105,6 +112,22 @@ extern "C" int mumpy_layernorm_fwd(const float* x, const float* gamma, const flo
     hipLaunchKernelGGL(ln_rows_kernel<PlainRows>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
                        PlainRows{x, C}, gamma, beta, y, rows, C, lpr, nv, eps);
     MUMPY_CHECK_LAUNCH("layernorm");
+    return 0;
+}
+
+extern "C" int mumpy_layernorm_bf16_fwd(const float* x, const float* gamma, const float* beta, void* y, int64_t rows,
+                                        int C, float eps, void* stream) {
+    if (rows == 0) return 0;
+    MUMPY_REQUIRE(x && gamma && beta && y, MUMPY_ENULL, "layernorm_bf16: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta), MUMPY_EALIGN,
+                  "layernorm_bf16: pointers must be 16-byte aligned");
+    int lpr, nv;
+    MUMPY_REQUIRE(rows >= 0 && pick_split(C, &lpr, &nv), MUMPY_EINVAL, "layernorm_bf16: unsupported C=%d", C);
+    const int rows_per_block = 4 * (64 / lpr);
+    const int64_t grid = (rows + rows_per_block - 1) / rows_per_block;
+    hipLaunchKernelGGL((ln_rows_kernel<PlainRows, true>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream),
+                       PlainRows{x, C}, gamma, beta, static_cast<float*>(y), rows, C, lpr, nv, eps);
+    MUMPY_CHECK_LAUNCH("layernorm_bf16");
     return 0;
 }
 

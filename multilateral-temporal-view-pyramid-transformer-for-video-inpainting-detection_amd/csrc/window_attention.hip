@@ -206,7 +206,8 @@ __device__ __forceinline__ const f32x4* at16(const char* base, uint32_t off) {
 
 // DBG = false is the shipped instantiation: the MUMPY_WA_DBG ablation switches (skip loads / MFMAs / stores) exist only in
 // the diagnostic instantiation, which the launcher selects when that variable is set.
-template <bool DBG>
+// IO16: qkv and out are bf16 in memory (config 3's activation storage); the arithmetic is the same fp32 MFMA flow.
+template <bool DBG, bool IO16 = false>
 __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     __shared__ uint32_t tok_in[4][64];    // token * (3C*4): byte offset of the token's qkv row
     __shared__ __attribute__((aligned(16))) uint32_t tok_out[4][64];   // token * (C*4):  byte offset of the token's out row
@@ -230,7 +231,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     __syncthreads();
     for (int d = 0; d < (slot % 3) * a.stagger; ++d) __builtin_amdgcn_s_sleep(127);
     const int64_t L = (int64_t)a.Hs * a.W;
-    const uint32_t rsb = 12u * a.C, rob = 4u * a.C;                      // row strides in bytes
+    const uint32_t rsb = (IO16 ? 6u : 12u) * a.C, rob = (IO16 ? 2u : 4u) * a.C;                      // row strides in bytes
     uint32_t* ti = tok_in[wave];
     uint32_t* to = tok_out[wave];
     for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {   // all scalar
@@ -243,13 +244,37 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         to[lane] = tok * rob;
     }
     __builtin_amdgcn_wave_barrier();
-    const char* base = reinterpret_cast<const char*>(a.qkv + b * L * 3 * a.C + head * HD);
+    const char* base = IO16 ? reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(a.qkv) + b * L * 3 * a.C + head * HD)
+                            : reinterpret_cast<const char*>(a.qkv + b * L * 3 * a.C + head * HD);
 
     // q/k/v go straight to registers (MFMA operand layout); branch-free
     f32x4 qf[2][4], kf[2][4];
     float vf[2][16];
     const int dbg = DBG ? a.dbg : 0;
     if (!(dbg & 1)) {
+        if (IO16) {
+            // a lane's 16 channels are 32 bytes: two 16-byte loads of 8 bf16, widened to fp32 by a shift
+            typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+            auto widen = [](u32x4v w, f32x4& lo, f32x4& hi) {
+                lo = f32x4{__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16), __uint_as_float(w.y & 0xffff0000u)};
+                hi = f32x4{__uint_as_float(w.z << 16), __uint_as_float(w.z & 0xffff0000u), __uint_as_float(w.w << 16), __uint_as_float(w.w & 0xffff0000u)};
+            };
+            const char* kbase = base + 2 * a.C;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const uint32_t off = ti[32 * t + c] + 32u * h;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    widen(*reinterpret_cast<const u32x4v*>(base + (off + 16u * i)), qf[t][2 * i], qf[t][2 * i + 1]);
+                    widen(*reinterpret_cast<const u32x4v*>(kbase + (off + 16u * i)), kf[t][2 * i], kf[t][2 * i + 1]);
+                }
+            }
+            const char* vbase = base + 4 * a.C;
+            for_pv_steps([&](int jt, int g, int e) {
+                const uint32_t w = *reinterpret_cast<const uint16_t*>(vbase + (ti[32 * jt + 8 * g + 4 * h + e] + 2u * c));
+                vf[jt][4 * g + e] = __uint_as_float(w << 16);
+            });
+        } else {
         const char* kbase = base + 4 * a.C;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -264,6 +289,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         for_pv_steps([&](int jt, int g, int e) {
             vf[jt][4 * g + e] = *reinterpret_cast<const float*>(vbase + (ti[32 * jt + 8 * g + 4 * h + e] + 4u * c));
         });
+        }
     } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t) { load_frag(qf[t], a.qkv, false); load_frag(kf[t], a.qkv, false); }
@@ -279,7 +305,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         const int id = a.mask_id[bw % a.n_mask];   // scalar load
         if (id >= 0) mask_w = a.mask_tab + (int64_t)id * 4096;
     }
-    char* obase = reinterpret_cast<char*>(a.out + b * L * a.C + head * HD);
+    char* obase = IO16 ? reinterpret_cast<char*>(reinterpret_cast<__bf16*>(a.out) + b * L * a.C + head * HD)
+                       : reinterpret_cast<char*>(a.out + b * L * a.C + head * HD);
     // the two 32-query tiles go one after the other: S needs 32 accumulator registers instead of 64
     auto tiles = [&](auto masked) {
         constexpr bool MASKED = decltype(masked)::value;
@@ -316,7 +343,10 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
                     const int i = 32 * it + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (i < WT) *reinterpret_cast<float*>(obase + (to4[r >> 2][r & 3] + 4u * c)) = o[r];
+                    if (i < WT) {
+                        if (IO16) *reinterpret_cast<__bf16*>(obase + (to4[r >> 2][r & 3] + 2u * c)) = (__bf16)o[r];
+                        else *reinterpret_cast<float*>(obase + (to4[r >> 2][r & 3] + 4u * c)) = o[r];
+                    }
                 }
             } else if (o[0] == 1234.5f && o[5] == 77.f) obase[0] = 1;
         }
@@ -874,7 +904,7 @@ __global__ __launch_bounds__(64) void win_attn_dtable_kernel(const float* __rest
 
 }  // namespace
 
-extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
+static int window_attention_launch(bool io16, const float* qkv, float* out, const float* bias, const float* mask_tab,
                                           const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
                                           float scale, void* stream) {
     MUMPY_REQUIRE(qkv && out && bias, MUMPY_ENULL, "window_attention: null pointer");
@@ -902,10 +932,25 @@ extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const fl
     if (groups > quads) groups = quads;
     a.groups = (int)groups; a.stagger = wa_stagger;
     const int64_t grid = groups * a.nH;
-    if (dbgmask) hipLaunchKernelGGL(win_attn_self_kernel<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
-    else hipLaunchKernelGGL(win_attn_self_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    if (io16) hipLaunchKernelGGL((win_attn_self_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else if (dbgmask) hipLaunchKernelGGL((win_attn_self_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else hipLaunchKernelGGL((win_attn_self_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention");
     return 0;
+}
+
+extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
+                                          const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
+                                          float scale, void* stream) {
+    return window_attention_launch(false, qkv, out, bias, mask_tab, mask_id, n_mask, B, Hs, W, C, shift, scale, stream);
+}
+
+// bf16 STORAGE: qkv (B, Hs*W, 3C) and out (B, Hs*W, C) are bf16; bias / mask tables fp32; same arithmetic.
+extern "C" int mumpy_window_attention_bf16_fwd(const void* qkv, void* out, const float* bias, const float* mask_tab,
+                                               const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
+                                               float scale, void* stream) {
+    return window_attention_launch(true, static_cast<const float*>(qkv), static_cast<float*>(out), bias, mask_tab, mask_id, n_mask,
+                                   B, Hs, W, C, shift, scale, stream);
 }
 
 extern "C" int mumpy_deform_attention_fwd(const float* q, const float* kv, const float* padmask, float* out, int B,

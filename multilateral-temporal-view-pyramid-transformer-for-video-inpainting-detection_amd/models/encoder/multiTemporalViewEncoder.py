@@ -65,6 +65,11 @@ class CrossSwinBlock(nn.Module):
         h, w = self.input_resolution
         b, l1, c1 = x1.shape
         self.drop_path(x1)
+        if ops.storage() == "bf16":                              # config 3: bf16 LN output / qkv / attention output
+            from models.modules.swinTransformer import _w16
+            a = self.attn.attend(ops.layernorm_bf16(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, l1 // w, w, 0, None)
+            out = ops.linear_bf16s(a, _w16(self.attn, "proj"), self.attn.proj.bias, out_bf16=False)
+            return ops.add(x1, out), out
         a = self.attn.attend(ops.layernorm(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, l1 // w, w, 0, None)
         out = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
         return ops.add(x1, out), out
@@ -80,6 +85,8 @@ class CrossSwinBlock(nn.Module):
             yt = self.cva.crossattn.attend_raster(x1, x2p, b, hs1, w, hs2)
             # x1 + [x1 in window order] + [scrambled proj_out]  (mTVE:138, 285-286; deform:403)
             x1 = ops.deform_combine(x1, yt, b, hs1, w, c1)
+        if ops.storage() == "bf16":
+            return self.mlp.forward_bf16(ops.layernorm_bf16(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), x1)
         return self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1)
 
     def forward(self, x1, x2):

@@ -26,6 +26,12 @@ class FeedForward(nn.Module):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU)
         return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
 
+    def forward_bf16(self, x16, residual):
+        """bf16 storage: bf16 LayerNorm output in, bf16 hidden tensor, fc2 adds into the fp32 residual stream."""
+        from models.modules.swinTransformer import _w16
+        h = ops.linear_bf16s(x16, _w16(self, "fc1"), self.fc1.bias, act=ops.ACT_GELU, out_bf16=True)
+        return ops.linear_bf16s(h, _w16(self, "fc2"), self.fc2.bias, residual=residual, out_bf16=False)
+
 
 class Attention(nn.Module):
     def __init__(self, dim, heads, dropout):
@@ -66,4 +72,6 @@ class Block(nn.Module):
             raise NotImplementedError("attention maps are not materialised")
         self.drop_path(x)
         x, _ = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), mask, residual=x)
+        if ops.storage() == "bf16" and isinstance(self.mlp, FeedForward):
+            return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
         return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x)

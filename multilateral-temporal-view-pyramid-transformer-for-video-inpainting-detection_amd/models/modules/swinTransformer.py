@@ -50,6 +50,16 @@ def relative_position_index(ws_h, ws_w):
     return (rel[0] + ws_h - 1) * (2 * ws_w - 1) + (rel[1] + ws_w - 1)
 
 
+def _w16(module, name):
+    """bf16 copy of module.<name>.weight, cached per weight version (Derived)."""
+    lin = getattr(module, name)
+    cache = module.__dict__.setdefault("_w16_cache", {})
+    d = cache.get(name)
+    if d is None:
+        d = cache[name] = Derived()
+    return d.get((lin.weight,), lambda: lin.weight.detach().to(torch.bfloat16).contiguous())
+
+
 class Mlp(nn.Module):
     def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
         super().__init__()
@@ -63,6 +73,13 @@ class Mlp(nn.Module):
     def forward(self, x, residual=None):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU)
         return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
+
+    def forward_bf16(self, x16, residual):
+        """bf16 storage (ops.set_storage("bf16")): x16 is the bf16 LayerNorm output, the 4C hidden tensor stays bf16, fc2
+        adds into the fp32 residual stream."""
+        w1, w2 = _w16(self, "fc1"), _w16(self, "fc2")
+        h = ops.linear_bf16s(x16, w1, self.fc1.bias, act=ops.ACT_GELU, out_bf16=True)
+        return ops.linear_bf16s(h, w2, self.fc2.bias, residual=residual, out_bf16=False)
 
 
 class WindowAttention(nn.Module):
@@ -95,8 +112,11 @@ class WindowAttention(nn.Module):
 
     def attend(self, x_normed, b, hs, w, shift, mask):
         """x_normed (B, hs*w, C) raster -> projected W-MSA output (B, hs*w, C) raster, optional fused residual later."""
-        qkv = ops.linear(x_normed, self.qkv.weight, self.qkv.bias)
         tab, ids = self.mask_pack(mask)
+        if x_normed.dtype == torch.bfloat16:                      # bf16 storage: bf16 in, bf16 qkv, bf16 out
+            qkv = ops.linear_bf16s(x_normed, _w16(self, "qkv"), self.qkv.bias, out_bf16=True)
+            return ops.window_attention_bf16(qkv, self.padded_bias(), b, hs, w, self.dim, shift, self.scale, tab, ids)
+        qkv = ops.linear(x_normed, self.qkv.weight, self.qkv.bias)
         return ops.window_attention(qkv, self.padded_bias(), b, hs, w, self.dim, shift, self.scale, tab, ids)
 
     def forward(self, x, mask=None):
@@ -138,6 +158,11 @@ class SwinTransformerBlock(nn.Module):
         assert l % (h * w) == 0, "input feature has wrong size"
         hs = l // w                                              # frames stacked on rows (swin:267)
         self.drop_path(x)                                        # raises in training mode with stochastic depth
+        if ops.storage() == "bf16":                              # config 3: bf16 tensors between the kernels of the block
+            a = self.attn.attend(ops.layernorm_bf16(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs, w,
+                                 self.shift_size, self.attn_mask)
+            x = ops.linear_bf16s(a, _w16(self.attn, "proj"), self.attn.proj.bias, residual=x, out_bf16=False)
+            return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
         a = self.attn.attend(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs, w,
                              self.shift_size, self.attn_mask)
         x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x)

@@ -16,7 +16,10 @@ c_d = ctypes.c_double
 # name -> argtypes; mirrors include/mumpy_hip.h one to one (tests/test_abi.py checks the header against this)
 SIGNATURES = {
     "mumpy_layernorm_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_fl, c_f],
+    "mumpy_layernorm_bf16_fwd": [c_f, c_f, c_f, c_f, c_l, c_i, c_fl, c_f],
     "mumpy_linear_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f],
+    "mumpy_linear_bf16s_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_window_attention_bf16_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_linear_ws_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_linear_workspace_bytes": [c_l, c_i, c_i],
     "mumpy_linear_rows_fwd": [c_f, c_l, c_l, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],

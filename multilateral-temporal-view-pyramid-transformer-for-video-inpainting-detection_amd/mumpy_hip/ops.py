@@ -31,6 +31,70 @@ _MODES = {"fp32": MATH_FP32, "bf16": MATH_BF16, "bf16x3": MATH_BF16X3, "bf16x2":
 
 def matrix_math() -> str:
     return {v: k for k, v in _MODES.items()}[_MATH]
+
+
+_STORAGE = "fp32"
+
+
+def set_storage(mode: str) -> None:
+    """"fp32" (default) or "bf16": BASELINE config 3 as written -- inside the Swin blocks (and the MLPs of the global
+    blocks) LayerNorm writes bf16, the qkv / fc1 GEMMs read bf16 activations and bf16 copies of their weights and write
+    bf16, window attention reads and writes bf16, and the proj / fc2 GEMMs read bf16 and add into the fp32 residual stream.
+    Accumulation, softmax and LayerNorm statistics stay fp32.  Implies set_matrix_math("bf16") for the remaining GEMMs."""
+    global _STORAGE
+    if mode not in ("fp32", "bf16"):
+        raise ValueError(f"unknown storage mode {mode!r}")
+    _STORAGE = mode
+    set_matrix_math("bf16" if mode == "bf16" else "fp32")
+
+
+def storage() -> str:
+    return _STORAGE
+
+
+def _chk16(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda or t.dtype != torch.bfloat16:
+        raise RuntimeError(f"mumpy_hip: {name} must be a bfloat16 GPU tensor, got {t.dtype} on {t.device}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def layernorm_bf16(x, gamma, beta, eps=1e-5):
+    """LayerNorm of an fp32 tensor, written as bf16 (statistics in fp32)."""
+    x = _chk(x, "x")
+    c = x.shape[-1]
+    out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    _call("mumpy_layernorm_bf16_fwd", _p(x), _p(_chk(gamma, "gamma")), _p(_chk(beta, "beta")), _p(out), x.numel() // c, c, eps,
+          _stream(), work=6.0 * x.numel())
+    return out
+
+
+def linear_bf16s(x16, w16, bias=None, act=ACT_NONE, residual=None, out_bf16=True):
+    """y = act(x16 @ w16.T + bias) + residual with bf16 x / W in memory, fp32 accumulate; y bf16 or fp32 (residual fp32)."""
+    x16, w16 = _chk16(x16, "x"), _chk16(w16, "weight")
+    n, k = w16.shape[0], w16.numel() // w16.shape[0]
+    if x16.shape[-1] != k:
+        raise RuntimeError(f"linear_bf16s: x has {x16.shape[-1]} features, weight expects {k}")
+    m = x16.numel() // k
+    out = torch.empty(*x16.shape[:-1], n, device=x16.device, dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+        if residual.numel() != m * n or out_bf16:
+            raise RuntimeError("linear_bf16s: the residual is fp32 and needs an fp32 output of the same shape")
+    _call("mumpy_linear_bf16s_fwd", _p(x16), _p(w16), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out),
+          m, n, k, act, 1 if out_bf16 else 0, _stream(), work=2.0 * m * n * k)
+    return out
+
+
+def window_attention_bf16(qkv16, bias_pad, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None):
+    """bf16 qkv (B, hs*w, 3C) -> bf16 (B, hs*w, C)."""
+    qkv16 = _chk16(qkv16, "qkv")
+    if qkv16.numel() != b * hs * w * 3 * c:
+        raise RuntimeError("window_attention_bf16: qkv shape mismatch")
+    out = torch.empty(b, hs * w, c, device=qkv16.device, dtype=torch.bfloat16)
+    n_mask = 0 if mask_id is None else mask_id.numel()
+    _call("mumpy_window_attention_bf16_fwd", _p(qkv16), _p(out), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
+          b, hs, w, c, shift, scale, _stream(), work=307328.0 * b * (hs // 7) * (w // 7) * (c // 32))
+    return out
 NEG = -1e30
 
 

@@ -872,3 +872,81 @@ def test_graphed_forward_recaptures_after_a_weight_change(model_t3):
         assert torch.equal(after, eager) and not torch.equal(after, before)
     finally:
         dec.load_state_dict(sd, strict=True)
+
+
+# ------------------------------------------------------------------------------ config 3: bf16 STORAGE
+def _bf16(t):
+    return t.to(torch.bfloat16)
+
+
+def test_linear_bf16_storage():
+    """mumpy_linear_bf16s_fwd: bf16 x and W in memory, fp32 accumulate -- against an fp64 product of the SAME bf16 operands
+    (so only the accumulation order and the output rounding differ): fp32 output to 2e-5, bf16 output to one bf16 ulp."""
+    for (m, n, k, act, res) in [(200, 96, 64, 0, True), (7840, 512, 512, 0, True), (1568, 1536, 384, 1, False), (392, 768, 3072, 0, True),
+                                (6272, 192, 96, 1, False)]:
+        x = _bf16(seeded_randn(m + n, m, k)).to(DEV)
+        w = _bf16(seeded_randn(m + n + 1, n, k) / k ** 0.5).to(DEV)
+        b = seeded_randn(m + n + 2, n).to(DEV)
+        r = seeded_randn(m + n + 3, m, n).to(DEV) if res else None
+        ref = x.double() @ w.double().t() + b.double()
+        if act:
+            ref = torch.nn.functional.gelu(ref)
+        y32 = ops.linear_bf16s(x, w, b, act=act, residual=r, out_bf16=False)
+        want = ref + r.double() if res else ref
+        assert rel_err(y32.cpu(), want.cpu().float()) < 2e-5, (m, n, k)
+        if not res:
+            y16 = ops.linear_bf16s(x, w, b, act=act, out_bf16=True)
+            assert y16.dtype == torch.bfloat16
+            assert rel_err(y16.float().cpu(), ref.cpu().float()) < 5e-3, (m, n, k)      # bf16: 8 bits of mantissa
+
+
+def test_layernorm_bf16_output():
+    x = seeded_randn(31, 1000, 384).to(DEV) * 3 + 1
+    g, b = seeded_randn(32, 384).to(DEV), seeded_randn(33, 384).to(DEV)
+    y = ops.layernorm_bf16(x, g, b)
+    ref = torch.nn.functional.layer_norm(x.double(), (384,), g.double(), b.double(), 1e-5)
+    assert y.dtype == torch.bfloat16 and torch.equal(y, ops.layernorm(x, g, b).to(torch.bfloat16))     # == fp32 kernel + one rounding
+    assert rel_err(y.float().cpu(), ref.float().cpu()) < 5e-3
+
+
+def test_window_attention_bf16_storage():
+    """bf16 qkv in / bf16 out: equals the fp32 kernel run on the widened bf16 inputs, up to the output rounding."""
+    from models.modules.swinTransformer import build_shift_mask, relative_position_index
+    b, hs, w, c = 2, 28, 14, 96
+    for shift in (0, 3):
+        qkv16 = _bf16(seeded_randn(700 + shift, b, hs * w, 3 * c)).to(DEV)
+        bias = ops.expand_relpos_bias(seeded_randn(701, 169, c // 32).to(DEV) * 0.2, relative_position_index(7, 7).to(DEV))
+        tab = ids = None
+        if shift:
+            tab, ids = ops.compact_attn_mask(build_shift_mask(hs, w, 7, shift).to(DEV))
+        ref = ops.window_attention(qkv16.float(), bias, b, hs, w, c, shift, 32 ** -0.5, tab, ids)
+        out = ops.window_attention_bf16(qkv16, bias, b, hs, w, c, shift, 32 ** -0.5, tab, ids)
+        assert out.dtype == torch.bfloat16 and torch.equal(out, ref.to(torch.bfloat16))
+
+
+def test_full_model_bf16_storage_b8_t5():
+    """BASELINE config 3's per-GPU workload (B=8, T=5) with bf16 storage inside the Swin blocks and bf16 matrix math
+    everywhere, against the fp32 oracle: build-defined tolerance (the reference has no bf16 path) 2e-2 relative
+    on the mask logits.  Mask flips: SURVEY suggests < 0.1 %; with the synthetic weights the logits crowd around zero
+    (measured 0.11 % here, 0.14 % for the bf16-math mode at B=1), so the bar is the one test_full_model_bf16_math_t5 uses:
+    < 0.5 % AND a pixel may flip only where the reference logit lies within the observed error of the threshold."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    enc = _load_filled(Encoder(num_frames=5), DEV)
+    dec = _load_filled(Decoder(input_token_temporal_dims=[1, 1, 5]), DEV)
+    x = seeded_randn(3535, 8, 5, 3, 224, 224)
+    try:
+        ops.set_storage("bf16")
+        with torch.no_grad():
+            fx, vx, dx = enc(x.to(DEV))
+            logits, _ = dec(fx, vx, dx)
+    finally:
+        ops.set_storage("fp32")
+    with torch.no_grad():
+        ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)[0]
+    err = rel_err(logits.cpu(), ref)
+    flipped = O.mask_from_logits(logits.cpu()) != O.mask_from_logits(ref)
+    flips = float(flipped.float().mean())
+    print(f"bf16 storage: logits rel err {err:.3e}, mask flips {100 * flips:.4f} %")
+    assert err < 2e-2 and flips < 5e-3
+    assert float(ref[flipped].abs().max()) <= float((logits.cpu() - ref).abs().max())
