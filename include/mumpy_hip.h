@@ -77,6 +77,13 @@ int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_ws_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
                         int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Same for a workspace the caller KEEPS across calls: its first 4096 bytes must be zero on entry (zero them once after
+ * allocating it) and are zero again on exit -- the persistent kernel's arrival flags clean up after themselves -- which
+ * saves the reset node the _ws_ form enqueues in front of a split launch.  One such workspace per stream: it must not be
+ * shared by launches that may overlap. */
+int mumpy_linear_wsz_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
+                         int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* bf16 STORAGE (BASELINE config 3 as written: bf16 weights and activations in HBM, fp32 accumulate): x (M,K) and W (N,K) are
  * bf16 (the caller keeps bf16 copies of the nn.Linear weights), bias and residual fp32, y bf16 (out_bf16 != 0) or fp32 (the
  * residual stream stays fp32).  Products on v_mfma_f32_32x32x16_bf16; no split-K.  The reference has no bf16 path: the

@@ -716,7 +716,7 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split, bool x3 = false) {
 
 int launch_linear(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0,
-                  const ConvGeom* conv = nullptr) {
+                  const ConvGeom* conv = nullptr, bool ws_clean = false) {
     if (rpb <= 0) { rpb = M; bstride = 0; }
     const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
     const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
@@ -751,12 +751,15 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
             else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
         }
         if (how) {
-            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0)) return rc;
+            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0, nullptr, ws_clean)) return rc;
             MUMPY_CHECK_LAUNCH("linear(ws)");
             return 0;
         }
     }
     Plan p = make_plan(M, N, K, ws != nullptr, math_x3);
+    // the split-K slabs start one page into the workspace: its first 4096 bytes are the persistent kernel's arrival flags,
+    // which a kept workspace (mumpy_linear_wsz_fwd) promises to leave zero
+    if (ws) { ws += 1024; ws_bytes -= 4096; }
     if (p.ksplit > 1 && (int64_t)p.ksplit * M * N * (int64_t)sizeof(float) > ws_bytes) p.ksplit = 1;
     const int64_t grid = p.gm * p.gn * p.ksplit;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "linear: too many tiles");
@@ -858,7 +861,7 @@ extern "C" int64_t mumpy_linear_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0 || K % BK) return 0;
     const Plan p = make_plan(M, N, K, true), q = make_plan(M, N, K, true, true);     // either matrix-math mode
     const int ks = p.ksplit > q.ksplit ? p.ksplit : q.ksplit;
-    int64_t bytes = ks > 1 ? (int64_t)ks * M * N * (int64_t)sizeof(float) : 0;
+    int64_t bytes = ks > 1 ? (int64_t)ks * M * N * (int64_t)sizeof(float) + 4096 : 0;
     // the persistent kernel's split schedule (gemm_ws.h): flags + one 64-KB slab per workgroup, when the shape may take it
     if (gemm_ws::eligible(M, N, K)) {
         const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
@@ -912,6 +915,19 @@ extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float*
 #undef MUMPY_GEMM_S
     MUMPY_CHECK_LAUNCH("linear_bf16s");
     return 0;
+}
+
+// Same as mumpy_linear_ws_fwd for a workspace the caller KEEPS: its first 4096 bytes are zero on entry (zero it once when it is
+// allocated) and the library leaves them zero on exit, which saves the flag-reset node in front of the persistent kernel's
+// split schedule.  Not to be shared by launches that may overlap (one per stream).
+extern "C" int mumpy_linear_wsz_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y,
+                                    int64_t M, int N, int K, int act, void* workspace, int64_t workspace_bytes,
+                                    void* stream) {
+    if (M == 0) return 0;
+    if (int rc = check_linear_args(x, W, residual, y, M, N, K, act)) return rc;
+    MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "linear: workspace must be 16-byte aligned");
+    return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
+                         workspace ? workspace_bytes : 0, as_stream(stream), 0, 0, nullptr, true);
 }
 
 extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, const float* W,

@@ -497,7 +497,7 @@ inline int64_t workspace_bytes(int num_cu) { return 4096 + (int64_t)num_cu * E_D
 
 inline int launch(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, int num_cu, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0, int force_split = -1,
-                  void* stamps = nullptr) {
+                  void* stamps = nullptr, bool ws_clean = false) {
     Params p;
     p.X = x; p.W = W; p.bias = bias; p.residual = residual; p.Y = y;
     p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / BK;
@@ -525,8 +525,12 @@ inline int launch(const float* x, const float* W, const float* bias, const float
         grid = (unsigned)num_cu;
         p.flags = static_cast<unsigned*>(ws);
         p.slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + 4096);
-        hipError_t e = hipMemsetAsync(p.flags, 0, 4096, s);
-        if (e != hipSuccess) { set_error("gemm_ws: flag reset failed: %s", hipGetErrorString(e)); return (int)e; }
+        // the owners put every flag they consume back to 0, so a workspace whose flag page was zero before a launch is zero
+        // after it: a caller that keeps such a workspace (ws_clean) saves the memset node in front of every launch
+        if (!ws_clean) {
+            hipError_t e = hipMemsetAsync(p.flags, 0, 4096, s);
+            if (e != hipSuccess) { set_error("gemm_ws: flag reset failed: %s", hipGetErrorString(e)); return (int)e; }
+        }
     }
 #define MUMPY_WS_LAUNCH(P_)                                                                                             \
     do {                                                                                                                \

@@ -165,10 +165,28 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
     wsb = _WS_BYTES.get(key)
     if wsb is None:
         wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
-    ws = torch.empty(wsb // 4, device=x.device, dtype=torch.float32) if wsb else None   # split-K slab (small-M shapes)
-    _call("mumpy_linear_ws_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
-          _p(out), m, n, k, act | _MATH, _p(ws), wsb, _stream(), work=2.0 * m * n * k)
+    ws = _kept_workspace(wsb, x.device) if wsb else None      # split-K slabs / the persistent kernel's flags + slabs
+    _call("mumpy_linear_wsz_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
+          _p(out), m, n, k, act | _MATH, _p(ws), 0 if ws is None else ws.numel() * 4, _stream(), work=2.0 * m * n * k)
     return out
+
+
+_KEPT_WS = {}
+
+
+def _kept_workspace(nbytes, device):
+    """One zero-initialised workspace per (device, stream), grown on demand and kept: launches on one stream execute in
+    order, so they can share it; the persistent GEMM's arrival flags (its first page) return to zero after every launch
+    (mumpy_linear_wsz_fwd), so nothing has to be reset between launches.  Allocated outside any graph capture (the eager
+    warm-up pass that precedes a capture creates the buffers the captured launches then point at)."""
+    s = torch.cuda.current_stream(device)
+    key = (str(device), s.cuda_stream)
+    ws = _KEPT_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.zeros(nbytes // 4, device=device, dtype=torch.float32)     # (captured fill: still correct, just not free)
+        ws = _KEPT_WS[key] = torch.zeros(max(nbytes // 4, 1024), device=device, dtype=torch.float32)
+    return ws
 
 
 def linear_rows(x_view, weight, bias=None, residual=None, out=None):
