@@ -62,6 +62,8 @@ struct Params {
     int nk;                // K / 32
     unsigned gm, gn;       // tiles along M, N
     unsigned tiles;        // gm * gn
+    unsigned rr_cnt, rr_G; // whole-tile schedule: tiles per workgroup (max) and grid size; 0 = split schedule (virtual id = position)
+    unsigned st_w;         // super-tile width in tiles (4, 2 or 1)
     unsigned units;        // tiles * nk: the workgroups split this chunk sequence evenly (split tiles: "stream-K")
     int lmin;              // shortest allowed head part of a split tile (chunks)
     unsigned* flags;       // [grid] arrival flags of the partial slabs (zeroed by the launcher), or null: whole tiles only
@@ -75,17 +77,31 @@ struct Params {
 // flight across it); "memory" pins the compiler's LDS accesses on their side of it
 __device__ __forceinline__ void ws_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-__device__ __forceinline__ void tile_coords(const Params& p, unsigned t, unsigned& tm, unsigned& tn) {
-    // order (N-group, M, N-in-group): the tiles one XCD works on share a few x row panels and a narrow slice of W
-    const unsigned full = (p.gn / NG) * NG;
-    if (t < p.gm * full) {
-        const unsigned grp = t / (p.gm * NG), rem = t - grp * p.gm * NG;
-        tm = rem / NG;
-        tn = grp * NG + rem % NG;
+// Tile sequence.  Position q -> (tm, tn): "super-tiles" of 32 tiles (SH rows x SW columns of tiles, SW = 4, 2 or 1 --
+// the widest that divides the tile columns), super-tiles row-major, tiles row-major inside; the last, shorter super-row is
+// compacted.  Whole-tile schedule: workgroup b' takes positions b', b' + G, b' + 2G, ... -- so in every round the 32
+// workgroups that share an XCD (b' is the XCD-major renumbering of blockIdx.x) hold ONE super-tile and walk K in step: an
+// x row panel is fetched into the XCD's L2 once and hit by the SW - 1 other workgroups that need it, a W panel by SH - 1.
+// (With each workgroup on its own contiguous run of tiles the PMC passes showed 173 MB fetched per launch for ~20 MB of
+// operands on M=7840 N=2048 K=512: every tile re-read its x panel from beyond L2 -- profiles/r02_pmc_bench_traffic.md.)
+// The roles number tiles by a "virtual id" v whose chunks [v nk, (v+1) nk) are contiguous per workgroup: v = q under the
+// split schedule, v = b' * rr_cnt + round under the whole-tile one.
+__device__ __forceinline__ void tile_coords(const Params& p, unsigned v, unsigned& tm, unsigned& tn) {
+    unsigned q = v;
+    if (p.rr_cnt) {
+        const unsigned bq = v / p.rr_cnt, rnd = v - bq * p.rr_cnt;
+        q = bq + rnd * p.rr_G;
+    }
+    const unsigned SW = p.st_w, SH = 32u / SW, SN = p.gn / SW, row_tiles = SN * 32u;
+    const unsigned full_rows = p.gm / SH, full = full_rows * row_tiles;
+    if (q < full) {
+        const unsigned sm = q / row_tiles, r = q - sm * row_tiles, sn = r >> 5, j = r & 31u;
+        tm = sm * SH + j / SW;
+        tn = sn * SW + j % SW;
     } else {
-        const unsigned wdt = p.gn - full, rem = t - p.gm * full;
-        tm = rem / wdt;
-        tn = full + rem % wdt;
+        const unsigned per = (p.gm - full_rows * SH) * SW, r = q - full, sn = r / per, j = r - sn * per;   // (per > 0 here)
+        tm = full_rows * SH + j / SW;
+        tn = sn * SW + j % SW;
     }
 }
 
@@ -470,8 +486,15 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     const unsigned G = gridDim.x, orig = blockIdx.x, xcd = orig & 7, q8 = G >> 3, r8 = G & 7;
     const unsigned b = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
     const bool split = p.flags != nullptr;
-    const unsigned u0 = first_chunk(b, G, p.tiles, p.units, p.nk, p.lmin, split);
-    const unsigned u1 = first_chunk(b + 1, G, p.tiles, p.units, p.nk, p.lmin, split);
+    unsigned u0, u1;
+    if (split) {
+        u0 = first_chunk(b, G, p.tiles, p.units, p.nk, p.lmin, true);
+        u1 = first_chunk(b + 1, G, p.tiles, p.units, p.nk, p.lmin, true);
+    } else {                                        // whole tiles, dealt round-robin: virtual ids b rr_cnt .. + own count
+        const unsigned cnt = b < p.tiles ? (p.tiles - b + G - 1) / G : 0;
+        u0 = b * p.rr_cnt * (unsigned)p.nk;
+        u1 = u0 + cnt * (unsigned)p.nk;
+    }
     const int n_chunks = (int)(u1 - u0);
     if (n_chunks == 0) return;
     const unsigned t0 = u0 / (unsigned)p.nk;
@@ -520,8 +543,12 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     if (split && P < 4) P = 4;
     p.lmin = 1 + PASSES / P;
     unsigned grid = p.tiles < (unsigned)num_cu ? p.tiles : (unsigned)num_cu;
+    p.st_w = (p.gn % 4 == 0) ? 4u : (p.gn % 2 == 0) ? 2u : 1u;
+    p.rr_G = grid;
+    p.rr_cnt = (p.tiles + grid - 1) / grid;
     p.flags = nullptr; p.slabs = nullptr;
     if (split) {
+        p.rr_cnt = 0;
         grid = (unsigned)num_cu;
         p.flags = static_cast<unsigned*>(ws);
         p.slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + 4096);

@@ -8,7 +8,7 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 
 
 def agg(counter):
-    f = glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_bench_{counter}", "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(ROOT, "gpurun_out", f"pmc_bench_{counter}", "*", "*counter_collection.csv")), key=os.path.getmtime)
     d = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         d[r["Kernel_Name"]][0] += 1
@@ -20,14 +20,15 @@ F, W = agg("FETCH_SIZE"), agg("WRITE_SIZE")
 short = lambda k: re.sub(r"\(anonymous namespace\)::|^void ", "", k).split("(")[0]
 forwards = next(n for k, (n, _) in F.items() if "final_conv_kernel" in k)
 rows = sorted(((2 * f + W.get(k, [0, 0])[1], short(k), n, 2 * f, W.get(k, [0, 0])[1]) for k, (n, f) in F.items()), reverse=True)
-gemm = [r for r in rows if r[1].startswith("linear_kernel") and ", true," not in r[1].split("<")[1][:24] or r[1].startswith("splitk_reduce")]
-# ABI launches of mumpy_linear_ws_fwd + mumpy_linear_rows_fwd per forward = non-conv linear_kernel dispatches
-abi_launches = sum(r[2] for r in gemm if r[1].startswith("linear_kernel"))
+is_gemm = lambda n: (n.startswith("linear_kernel") and ", true," not in n.split("<")[1][:24]) or "gemm_ws_kernel" in n
+gemm = [r for r in rows if is_gemm(r[1]) or r[1].startswith("splitk_reduce")]
+# ABI launches of mumpy_linear_wsz_fwd + mumpy_linear_rows_fwd per forward = non-conv linear_kernel + gemm_ws_kernel dispatches
+abi_launches = sum(r[2] for r in gemm if is_gemm(r[1]))
 gemm_bytes = sum(r[3] + r[4] for r in gemm)
 out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) -- python3 bench.py --steps 2 --warmup 1 "
                  "--no-cpu-baseline --no-alt --no-graph, MUMPY_SERIAL=1; FETCH_SIZE x2 (gfx950 correction)",
        "forwards_in_profile": forwards,
-       "mumpy_linear_ws_fwd": {"launches": abi_launches, "hbm_bytes_per_launch": round(gemm_bytes / abi_launches),
+       "mumpy_linear_wsz_fwd": {"launches": abi_launches, "hbm_bytes_per_launch": round(gemm_bytes / abi_launches),
                                "read_bytes_per_launch": round(sum(r[3] for r in gemm) / abi_launches),
                                "write_bytes_per_launch": round(sum(r[4] for r in gemm) / abi_launches)},
        "per_forward_hbm_bytes_all_kernels": round(sum(r[0] for r in rows) / forwards)}
@@ -39,8 +40,8 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_bench_traffic.md"), "w") as
     tot = sum(r[0] for r in rows)
     for r in rows[:24]:
         f.write(f"| `{r[1][:80]}` | {r[2]} | {r[3] / r[2] / 1e6:.2f} | {r[4] / r[2] / 1e6:.2f} | {100 * r[0] / tot:.1f} % |\n")
-    g = out["mumpy_linear_ws_fwd"]
-    f.write(f"\nDominant ABI entry `mumpy_linear_ws_fwd` (+`_rows_fwd`; its `linear_kernel` and `splitk_reduce_kernel` dispatches): "
+    g = out["mumpy_linear_wsz_fwd"]
+    f.write(f"\nDominant ABI entry `mumpy_linear_wsz_fwd` (+`_rows_fwd`; its `gemm_ws_kernel`, `linear_kernel` and `splitk_reduce_kernel` dispatches): "
             f"{g['hbm_bytes_per_launch'] / 1e6:.1f} MB per launch ({g['read_bytes_per_launch'] / 1e6:.1f} read + "
             f"{g['write_bytes_per_launch'] / 1e6:.1f} written) -- this is `roofline.traffic` of `bench.py`.\n")
 print(json.dumps(out, indent=1))
