@@ -729,7 +729,8 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     // tiles fill >= 86 % of the rounds they need (K >= 128), or -- with a workspace -- when an even split of the chunk
     // sequence gives every CU >= 24 chunks and cuts a tile into <= 3 parts; leave the deep-K shapes with two or more tiles
     // per CU to the tiled kernels (two co-resident workgroups hide each other's prologue and epilogue there: 121 TFLOP/s).
-    if (!conv && rpb >= M && !math_bf16 && !math_x3 && gemm_ws::eligible(M, N, K)) {
+    const gemm_ws::Conv cvd{cg.H, cg.W, cg.Cin, cg.kh, cg.kw};
+    if (rpb >= M && !math_bf16 && !math_x3 && (conv ? gemm_ws::conv_eligible(M, N, cvd) : gemm_ws::eligible(M, N, K))) {
         static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
         static int num_cu = 0;
         if (!num_cu) {
@@ -746,12 +747,18 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
         int how = 0;                                                        // 0: tiled kernels, 1: whole tiles, 2: split
         if (ws_mode == 1) how = 1;
         else if (ws_mode == 3) how = have_ws ? 2 : 1;
-        else if (ws_mode == 2) {
+        else if (ws_mode == 2 && conv) {
+            // convolutions (decoder: N = 128 / 256, 196 or 784 tiles = 0.77 of the rounds they need): the even split first,
+            // whole tiles down to 75 % round utilisation (profiles/r02_conv_shapes.txt; the tiled kernels sit at 74-80 TFLOP/s)
+            if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0) how = 2;
+            else if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.75 && K >= 128) how = 1;
+        } else if (ws_mode == 2) {
             if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.86 && K >= 128 && !(K >= 1024 && rounds >= 1.8)) how = 1;
             else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
         }
         if (how) {
-            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0, nullptr, ws_clean)) return rc;
+            if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0, nullptr, ws_clean,
+                                         conv ? &cvd : nullptr)) return rc;
             MUMPY_CHECK_LAUNCH("linear(ws)");
             return 0;
         }

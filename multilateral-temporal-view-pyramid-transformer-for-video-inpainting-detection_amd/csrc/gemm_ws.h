@@ -66,6 +66,10 @@ struct Params {
     unsigned st_w;         // super-tile width in tiles (4, 2 or 1)
     unsigned units;        // tiles * nk: the workgroups split this chunk sequence evenly (split tiles: "stream-K")
     int lmin;              // shortest allowed head part of a split tile (chunks)
+    // implicit-GEMM convolution (loader_role<true>): x is an NHWC image batch, row m = output pixel (img, y, x), K index =
+    // (tap, channel); all zero for a plain GEMM
+    int cv_H, cv_W, cv_C, cv_kh, cv_kw, cv_cpc;             // image size, channels, taps, chunks per tap (Cin / 32)
+    unsigned cv_mhw, cv_shw, cv_mw, cv_sw;                  // magic numbers: m / (H W) and rem / W as mulhi + shift
     unsigned* flags;       // [grid] arrival flags of the partial slabs (zeroed by the launcher), or null: whole tiles only
     float* slabs;          // [grid][128*128] partial accumulator images of split tiles
 #ifdef MUMPY_WS_STAMP
@@ -241,10 +245,18 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int kc0
 // (tools/micro/coissue.hip), so these waves issue nothing but the DMA itself.
 // The LDS image is lane-linear per wave-instruction, so the XOR swizzle is applied to the SOURCE address: lane l of a piece
 // covers tile row r0 + l/8, physical chunk l%8, and fetches logical chunk (l%8) ^ ((row >> 1) & 7).
+//
+// CONV (implicit GEMM, NHWC, stride 1, zero "same" padding): the A row of output pixel m for chunk (tap (r, s), channels
+// c0 .. c0+31) is the 128 contiguous bytes of the input pixel (y + r - ph, x + s - pw) -- or zeros.  Per tile each lane
+// decodes its four rows once (two magic-number divisions) and keeps a bit mask of the taps that fall inside the image;
+// per chunk that is one bit test, one add of the chunk's (wave-uniform) byte displacement and one select of the OOB offset
+// per piece: out-of-image taps are dropped by the buffer range check and the DMA writes zeros.
+template <bool CONV>
 __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigned tile0, int kc0, int n_chunks, int hl) {
     const int lane = hl & 63, lw = __builtin_amdgcn_readfirstlane(hl >> 6);
     const int prow = lane >> 3;                                  // row inside a piece
     uint32_t aoff[4], boff[4];                                   // byte offsets of this lane's source chunk, per piece
+    uint32_t amask[4];                                           // CONV: bit (r kw + s) = tap (r, s) of this row is inside the image
     auto set_tile = [&](unsigned t) {
         unsigned tm, tn;
         tile_coords(p, t, tm, tn);
@@ -254,7 +266,20 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
             const uint32_t ch = (uint32_t)((lane & 7) ^ ((r >> 1) & 7));
             int m = (int)tm * BM + r;
             if (m > p.M - 1) m = p.M - 1;           // rows past the edge are clamped: their products are never stored
-            aoff[q] = ((uint32_t)m * (uint32_t)p.K + 4u * ch) * 4u;
+            if (CONV) {
+                const uint32_t img = __umulhi((uint32_t)m, p.cv_mhw) >> p.cv_shw;
+                const uint32_t rem = (uint32_t)m - img * (uint32_t)(p.cv_H * p.cv_W);
+                const uint32_t yy = __umulhi(rem, p.cv_mw) >> p.cv_sw, xx = rem - yy * (uint32_t)p.cv_W;
+                uint32_t colbits = 0, mask = 0;
+                for (int sx = 0; sx < p.cv_kw; ++sx)
+                    colbits |= (uint32_t)((uint32_t)((int)xx + sx - (p.cv_kw >> 1)) < (uint32_t)p.cv_W) << sx;
+                for (int ry = 0; ry < p.cv_kh; ++ry)
+                    if ((uint32_t)((int)yy + ry - (p.cv_kh >> 1)) < (uint32_t)p.cv_H) mask |= colbits << (ry * p.cv_kw);
+                amask[q] = mask;
+                aoff[q] = ((uint32_t)m * (uint32_t)p.cv_C + 4u * ch) * 4u;
+            } else {
+                aoff[q] = ((uint32_t)m * (uint32_t)p.K + 4u * ch) * 4u;
+            }
             int n = (int)tn * BN + r;
             if (n > p.N - 1) n = p.N - 1;
             boff[q] = ((uint32_t)n * (uint32_t)p.K + 4u * ch) * 4u;
@@ -263,13 +288,31 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)0x7fffffff, 0x00020000);
     const auto rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.W), 0, (int)0x7fffffff, 0x00020000);
     typedef __attribute__((address_space(3))) void* lptr_t;
+    // CONV cursor state (wave-uniform): tap row / column and chunk inside the tap of the chunk the cursor points at
+    int cv_r = 0, cv_s = 0, cv_c = 0;
+    if (CONV) {
+        const int tap0 = kc0 / p.cv_cpc;
+        cv_c = kc0 - tap0 * p.cv_cpc;
+        cv_r = tap0 / p.cv_kw;
+        cv_s = tap0 - cv_r * p.cv_kw;
+    }
     auto dma = [&](int kc, int stage) {
         if (DBG & 1) return;
         const int so = kc * 128;
         float* st = lds + stage * STAGE_DW + 8 * lw * BK;        // this wave's 8 rows of piece 0
+        if (CONV) {
+            const int tap = cv_r * p.cv_kw + cv_s;
+            const int delta = (((cv_r - (p.cv_kh >> 1)) * p.cv_W + (cv_s - (p.cv_kw >> 1))) * p.cv_C + 32 * cv_c) * 4;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(st + 32 * q * BK), 16, aoff[q], so, 0, 0);
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t off = ((amask[q] >> tap) & 1u) ? aoff[q] + (uint32_t)delta : OOB;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(st + 32 * q * BK), 16, off, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lptr_t)(st + 32 * q * BK), 16, aoff[q], so, 0, 0);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lptr_t)(st + (BM + 32 * q) * BK), 16, boff[q], so, 0, 0);
@@ -281,7 +324,13 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
     auto advance = [&]() {
         if (ld_idx + 1 < n_chunks) {
             ++ld_idx;
-            if (++ld_kc == p.nk) { ld_kc = 0; ++ld_tile; set_tile(ld_tile); }
+            if (++ld_kc == p.nk) {
+                ld_kc = 0; ++ld_tile; set_tile(ld_tile);
+                if (CONV) { cv_r = 0; cv_s = 0; cv_c = 0; }
+            } else if (CONV && ++cv_c == p.cv_cpc) {
+                cv_c = 0;
+                if (++cv_s == p.cv_kw) { cv_s = 0; ++cv_r; }
+            }
         }
     };
     set_tile(ld_tile);
@@ -476,7 +525,7 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
     }
 }
 
-template <int P>
+template <int P, bool CONV = false>
 __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -504,7 +553,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
         // (priority: no measurable effect either way beside an fp32 MFMA stream -- tools/micro/coissue.hip; kept so that
         // the few instructions of these roles are not additionally delayed by arbitration)
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(3);
-        if (wave < 8) loader_role(p, lds, t0, kc0, n_chunks, tid - 256);
+        if (wave < 8) loader_role<CONV>(p, lds, t0, kc0, n_chunks, tid - 256);
         else epilogue_role<P>(p, lds, b, G, u0, u1, tid - 512);
     }
 }
@@ -515,13 +564,35 @@ inline bool eligible(int64_t M, int N, int K) {
            (int64_t)N * K * 4 < (1ll << 31) && M * (int64_t)N * 4 < (1ll << 31);
 }
 
+// convolution geometry for the implicit-GEMM mode (stride 1, odd taps, zero "same" padding; x NHWC, W [Cout][kh][kw][Cin])
+struct Conv { int H, W, C, kh, kw; };
+inline bool conv_eligible(int64_t M, int N, const Conv& c) {
+    const int64_t K = (int64_t)c.kh * c.kw * c.C;
+    return c.C % BK == 0 && c.kh * c.kw <= 32 && K >= 3 * BK && K < (1 << 24) && N % 4 == 0 && M >= 1 && c.W >= 2 && c.H * (int64_t)c.W < (1 << 30) &&
+           M * (int64_t)c.C * 4 < (1ll << 31) && (int64_t)N * K * 4 < (1ll << 31) && M * (int64_t)N * 4 < (1ll << 31);
+}
+// n / d for every n < 2^31 as mulhi(n, magic) >> shift (round-up method, N = 31 bits; d >= 2)
+inline void magic_div(unsigned d, unsigned& magic, unsigned& shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    magic = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
+    shift = s - 1;
+}
+
 // workspace for the split schedule: arrival flags + one slab per workgroup
 inline int64_t workspace_bytes(int num_cu) { return 4096 + (int64_t)num_cu * E_DW * 4; }
 
 inline int launch(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, int num_cu, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0, int force_split = -1,
-                  void* stamps = nullptr, bool ws_clean = false) {
+                  void* stamps = nullptr, bool ws_clean = false, const Conv* cv = nullptr) {
     Params p;
+    p.cv_H = p.cv_W = p.cv_C = p.cv_kh = p.cv_kw = p.cv_cpc = 0;
+    p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
+    if (cv) {
+        p.cv_H = cv->H; p.cv_W = cv->W; p.cv_C = cv->C; p.cv_kh = cv->kh; p.cv_kw = cv->kw; p.cv_cpc = cv->C / BK;
+        magic_div((unsigned)(cv->H * cv->W), p.cv_mhw, p.cv_shw);
+        magic_div((unsigned)cv->W, p.cv_mw, p.cv_sw);
+    }
     p.X = x; p.W = W; p.bias = bias; p.residual = residual; p.Y = y;
     p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / BK;
     p.gm = (unsigned)((M + BM - 1) / BM); p.gn = (unsigned)((N + BN - 1) / BN);
@@ -568,7 +639,15 @@ inline int launch(const float* x, const float* W, const float* bias, const float
             if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL(gemm_ws_kernel<P_>, dim3(grid), dim3(768), LDS_BYTES, s, p);                                 \
+        static bool attr_set_cv = false;                                                                                \
+        if (cv && !attr_set_cv) {                                                                                       \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<P_, true>),                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
+            if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
+            attr_set_cv = true;                                                                                         \
+        }                                                                                                               \
+        if (cv) hipLaunchKernelGGL((gemm_ws_kernel<P_, true>), dim3(grid), dim3(768), LDS_BYTES, s, p);                 \
+        else hipLaunchKernelGGL((gemm_ws_kernel<P_, false>), dim3(grid), dim3(768), LDS_BYTES, s, p);                   \
     } while (0)
     if (P == 1) MUMPY_WS_LAUNCH(1);
     else if (P == 2) MUMPY_WS_LAUNCH(2);

@@ -293,6 +293,26 @@ def test_conv2d_nhwc(cin, cout, kh, kw, h):
     assert rel_err(y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("cin,cout,kh,kw,h", [(128, 128, 3, 3, 56), (128, 128, 3, 3, 112), (256, 128, 7, 1, 56), (128, 128, 1, 7, 56),
+                                             (768, 256, 3, 3, 28), (32, 128, 3, 3, 112)])
+def test_conv2d_nhwc_b8_wave_specialised_loader(cin, cout, kh, kw, h):
+    """The decoder's large convolutions at B = 8 -- the shapes the planner gives to the wave-specialised kernel's
+    convolution loader (whole tiles and the split schedule; border taps zero-filled by the buffer range check) -- vs
+    torch's CPU conv in float64."""
+    b = 8
+    x = seeded_randn(cin + h, b, cin, h, h)
+    w = seeded_randn(cout + kh, cout, cin, kh, kw) / (cin * kh * kw) ** 0.5
+    bias = seeded_randn(3, cout)
+    res = seeded_randn(4, b, cout, h, h)
+    w_krsc = w.permute(0, 2, 3, 1).contiguous().to(DEV)
+    xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+    y = ops.conv2d_nhwc(xd, w_krsc, bias.to(DEV), residual=res.to(DEV).contiguous(memory_format=torch.channels_last))
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=(kh // 2, kw // 2)) + res.double()
+    assert rel_err(y.cpu(), ref) < 1e-5
+    y2 = ops.conv2d_nhwc(xd, w_krsc, bias.to(DEV), residual=res.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert torch.equal(y, y2)                      # fixed-order fix-up of split tiles: bitwise reproducible
+
+
 def test_linear_rows_strided_time_slices():
     """One time slice of (B, T, n, C) tokens as a (B*n, C) GEMM operand without a copy, chained via the residual."""
     b, t, n, c, nout = 3, 5, 196, 128, 256
