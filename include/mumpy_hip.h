@@ -282,6 +282,16 @@ int mumpy_transpose_fwd(const float* in, float* out, int64_t R, int64_t C, void*
 int64_t mumpy_col_sum_workspace_bytes(int64_t R, int C);
 int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, int64_t workspace_bytes, int64_t R, int C, void* stream);
 
+/* Backward of y = x W^T + b (nn.Linear under train.py:117-120's loss.backward()) from the row-major tensors as they are, no
+ * transposed copies: dx (M,K) = dy (M,N) W (N,K); dW (N,K) = dy^T x; db (N) = column sums of dy.  Any of dx / dW / db may be
+ * null (skipped).  accumulate bit 0: dW += (else overwritten); bit 1: db += -- the caller's flat gradient buffer, so no
+ * separate add kernels.  dx is always overwritten.  N % 32 == 0, K % 32 == 0, M free.  fp32 MFMA, deterministic
+ * (deep contractions are split over workgroups into workspace slabs and reduced in split order).
+ * workspace: mumpy_linear_bwd_workspace_bytes(M,N,K) bytes of device scratch (required for db; without it dW is not split). */
+int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K);
+int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M, int N, int K,
+                     int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* window attention backward (row 5 of 8a in training; swin:145-163 differentiated): qkv (B,Hs*W,3C) and dout (B,Hs*W,C)
  * in raster order as in the forward, bias / mask_tab / mask_id as in the forward, rel_index = the (49*49) int32 image of
  * `relative_position_index`.  Writes dqkv (B,Hs*W,3C) (every element) and dtable (169, C/32) = gradient of

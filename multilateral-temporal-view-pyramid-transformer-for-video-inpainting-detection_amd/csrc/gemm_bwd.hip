@@ -1,0 +1,294 @@
+// gemm_bwd.hip — the backward of y = x W^T + b (every nn.Linear of the path: swin:46-49,142,164; blocks:27-33,57-71;
+// train.py:117-120 runs loss.backward() over them) from the row-major tensors AS THEY ARE:
+//     dX[M,K] = dY[M,N] W[N,K]        contraction over N:  A = dY rows (contraction contiguous), B = W   ("NN")
+//     dW[N,K] = dY[M,N]^T X[M,K]      contraction over M:  A = dY, B = X, both with the contraction as the SLOW index ("TN")
+//     db[N]   = column sums of dY
+// The first version formed W^T, dY^T and X^T with a transpose kernel (and a zero-padded copy when M % 32 != 0) and ran
+// the forward GEMM on them: at config 5's micro-batch (B = 2) a training step was ~9,900 launches of mostly 3-8 us
+// kernels, 1,300 of them transposes (profiles/r02_train_b2_before.md).  Here an operand whose contraction index is the
+// slow one is staged [k][column] in LDS exactly as it lies in memory (16-B coalesced loads along the column) and the MFMA
+// fragments are read from that image directly: lane (c, h) of v_mfma_f32_32x32x2_f32 supplies ONE value per operand, for
+// row c and contraction slot h, so a ds_read_b64 at [k][2c] feeds TWO accumulator blocks whose rows are the even / odd
+// rows of the wave's 64 -- the output row (column) permutation is undone by the store addresses, nothing is transposed.
+// dW / db can be accumulated into (the caller's flat gradient buffer: no separate add kernels), deep contractions are
+// split over workgroups with per-split slabs and a fixed-order reduce (bitwise reproducible).  fp32 MFMA, exact products.
+#include "common.h"
+using namespace mumpy;
+
+namespace {
+
+constexpr int BK = 32;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct XArgs {
+    const float* A;      // A_T: [KK][lda >= R]   else: [R][lda >= KK]
+    const float* B;      // always contraction-slow: [KK][ldb >= C]
+    float* out;          // [R][ldo]
+    float* slabs;        // ks > 1: [ks][R][C] partial products
+    int64_t lda, ldb, ldo;
+    int R, C, KK;
+    int ks, chunks_per_split, nchunks;
+    int accum;           // ks == 1: out += product
+    int gc;              // tiles along C
+};
+
+// WT: wave tile (32 or 64); the workgroup tile is 2 WT x 2 WT (4 waves).  A_T: A's contraction index is the slow one.
+template <int WT, bool A_T>
+__global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
+    constexpr int BT = 2 * WT, NB = WT / 32;
+    constexpr int LDN = BK + 4;                  // [row][k] image: 36-dword rows (conflict-free ds_read_b128 down the rows)
+    constexpr int LDT = BT + 4;                  // [k][col] image
+    constexpr int A_DW = A_T ? BK * LDT : BT * LDN;
+    constexpr int PIECES = BT / 32;              // 16-B pieces per thread and operand per chunk
+    __shared__ __attribute__((aligned(16))) float As[A_DW];
+    __shared__ __attribute__((aligned(16))) float Bs[BK * LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x, z = blockIdx.y;
+    const int tr = tile / a.gc, tc = tile - tr * a.gc;
+    const int row0 = tr * BT, col0 = tc * BT;
+    const int ch0 = z * a.chunks_per_split;
+    int ch1 = ch0 + a.chunks_per_split;
+    if (ch1 > a.nchunks) ch1 = a.nchunks;
+
+    f32x4 pa[PIECES], pb[PIECES];
+    auto fetch = [&](int ch) {
+        const int k0 = ch * BK;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = tid + 256 * i;
+            if (A_T) {
+                const int kr = p / (BT / 4), cq = p - kr * (BT / 4);
+                const int k = k0 + kr, r = row0 + 4 * cq;
+                pa[i] = (k < a.KK && r < a.R) ? *reinterpret_cast<const f32x4*>(a.A + (int64_t)k * a.lda + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                int r = row0 + (p >> 3);
+                if (r > a.R - 1) r = a.R - 1;            // rows past the edge: clamped, their products are never stored
+                pa[i] = *reinterpret_cast<const f32x4*>(a.A + (int64_t)r * a.lda + k0 + 4 * (p & 7));
+            }
+            const int kr = p / (BT / 4), cq = p - kr * (BT / 4);
+            const int k = k0 + kr, cc = col0 + 4 * cq;
+            pb[i] = (k < a.KK && cc < a.C) ? *reinterpret_cast<const f32x4*>(a.B + (int64_t)k * a.ldb + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int p = tid + 256 * i;
+            const int kr = p / (BT / 4), cq = p - kr * (BT / 4);
+            if (A_T) *reinterpret_cast<f32x4*>(&As[kr * LDT + 4 * cq]) = pa[i];
+            else *reinterpret_cast<f32x4*>(&As[(p >> 3) * LDN + 4 * (p & 7)]) = pa[i];
+            *reinterpret_cast<f32x4*>(&Bs[kr * LDT + 4 * cq]) = pb[i];
+        }
+    };
+
+    f32x16 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // this lane's contraction slots of a chunk: k = 16 h + t, t = 0..15 (the same pairing for A and B)
+    const float* const a_n = As + (wm * WT + c) * LDN + 16 * h;                       // + 32 i LDN + 4 q
+    const float* const a_t = As + 16 * h * LDT + wm * WT + (NB == 2 ? 2 * c : c);     // + t LDT
+    const float* const b_t = Bs + 16 * h * LDT + wn * WT + (NB == 2 ? 2 * c : c);
+
+    if (ch0 < ch1) fetch(ch0);
+    for (int ch = ch0; ch < ch1; ++ch) {
+        __syncthreads();                         // the previous chunk's fragment reads are done
+        stage();
+        __syncthreads();
+        if (ch + 1 < ch1) fetch(ch + 1);         // global loads fly under this chunk's MFMAs
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[NB];
+            if (!A_T) {
+#pragma unroll
+                for (int i = 0; i < NB; ++i) fa[i] = *reinterpret_cast<const f32x4*>(a_n + 32 * i * LDN + 4 * q);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int t = 4 * q + e;
+                float av[NB], bv[NB];
+                if (A_T) {
+                    if (NB == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(a_t + t * LDT); av[0] = v.x; av[NB - 1] = v.y; }
+                    else av[0] = a_t[t * LDT];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) av[i] = fa[i][e];
+                }
+                if (NB == 2) { const f32x2 v = *reinterpret_cast<const f32x2*>(b_t + t * LDT); bv[0] = v.x; bv[NB - 1] = v.y; }
+                else bv[0] = b_t[t * LDT];
+#pragma unroll
+                for (int i = 0; i < NB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // accumulator (i, j)[r] -> row rho = (r&3) + 8 (r>>2) + 4 h, column gamma = c of the 32x32 block; block (i, j) holds
+    // wave rows 32 i + rho (A row-major) or 2 rho + i (A contraction-slow), wave columns 2 gamma + j (NB == 2) / gamma
+    float* dst;
+    int64_t ldd;
+    if (a.ks > 1) { dst = a.slabs + (int64_t)z * a.R * a.C; ldd = a.C; }
+    else { dst = a.out; ldd = a.ldo; }
+    const bool accum = a.ks == 1 && a.accum;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const int row = row0 + wm * WT + (A_T ? (NB == 2 ? 2 * rho + i : rho) : 32 * i + rho);
+            const int col = col0 + wn * WT + (NB == 2 ? 2 * c : c);
+            if (row < a.R && col < a.C) {
+                float* o = dst + (int64_t)row * ldd + col;
+                if (NB == 2) {
+                    f32x2 v{acc[i][0][r], acc[i][NB - 1][r]};
+                    if (accum) v += *reinterpret_cast<const f32x2*>(o);
+                    *reinterpret_cast<f32x2*>(o) = v;
+                } else {
+                    float v = acc[i][0][r];
+                    if (accum) v += *o;
+                    *o = v;
+                }
+            }
+        }
+}
+
+// out = (accum ? out : 0) + slab[0] + slab[1] + ... in split order (fixed: bitwise reproducible); n4 = R C / 4, dense
+__global__ __launch_bounds__(256) void xgemm_reduce_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ out, int64_t n4,
+                                                           int ks, int accum) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = slabs[i];
+        for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * n4 + i];
+        if (accum) s += out[i];
+        out[i] = s;
+    }
+}
+
+// column sums of dY (M, N): one partial row per block of rows, then a fixed-order reduce over the partial rows
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t R,
+                                                             int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int cc = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (cc < C)
+        for (int64_t r = r0 + rl; r < r0 + rows_per_block && r < R; r += 4) s += x[r * C + cc];
+    red[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && cc < C) partial[(int64_t)blockIdx.y * C + cc] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int nparts,
+                                                           int C, int accum) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int cc = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (cc < C)
+        for (int p = g; p < nparts; p += 4) s += partial[(int64_t)p * C + cc];
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && cc < C) {
+        const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+        out[cc] = accum ? out[cc] + t : t;
+    }
+}
+
+struct XPlan { int wt, ks, cps, nchunks, gr, gc; };
+
+XPlan plan(int R, int C, int KK) {
+    XPlan p;
+    const int64_t t128 = (int64_t)((R + 127) / 128) * ((C + 127) / 128);
+    p.wt = t128 >= 96 ? 64 : 32;                       // wide tiles only when they fill a good part of the chip
+    const int bt = 2 * p.wt;
+    p.gr = (R + bt - 1) / bt; p.gc = (C + bt - 1) / bt;
+    p.nchunks = (KK + BK - 1) / BK;
+    const int64_t tiles = (int64_t)p.gr * p.gc;
+    const int64_t target = p.wt == 64 ? 256 : 768;     // workgroups wanted (2 / 3+ resident per CU)
+    int ks = (int)(target / tiles);
+    if (ks > p.nchunks / 4) ks = p.nchunks / 4;
+    if (ks > 64) ks = 64;
+    if (ks < 1) ks = 1;
+    p.cps = (p.nchunks + ks - 1) / ks;
+    p.ks = (p.nchunks + p.cps - 1) / p.cps;            // no empty splits
+    return p;
+}
+
+int64_t colsum_blocks(int64_t R) {
+    int64_t b = (R + 127) / 128;
+    if (b > 1024) b = 1024;
+    return b < 1 ? 1 : b;
+}
+
+int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int R, int C, int KK,
+                 int accum, float* ws, int64_t ws_bytes, hipStream_t s) {
+    XPlan p = plan(R, C, KK);
+    if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * C * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
+    XArgs a;
+    a.A = A; a.B = B; a.out = out; a.slabs = ws; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
+    a.R = R; a.C = C; a.KK = KK; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accum; a.gc = p.gc;
+    const dim3 grid((unsigned)(p.gr * p.gc), (unsigned)p.ks);
+    if (p.wt == 64) {
+        if (a_t) hipLaunchKernelGGL((xgemm_kernel<64, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((xgemm_kernel<64, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (a_t) hipLaunchKernelGGL((xgemm_kernel<32, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((xgemm_kernel<32, false>), grid, dim3(256), 0, s, a);
+    }
+    MUMPY_CHECK_LAUNCH("linear_bwd(product)");
+    if (p.ks > 1) {
+        const int64_t n4 = (int64_t)R * C / 4;
+        int64_t g = (n4 + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(xgemm_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(ws),
+                           reinterpret_cast<f32x4*>(out), n4, p.ks, accum);
+        MUMPY_CHECK_LAUNCH("linear_bwd(reduce)");
+    }
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const XPlan p = plan(N, K, (int)M);
+    const int64_t slabs = p.ks > 1 ? (int64_t)p.ks * N * K * 4 : 0;
+    const int64_t cs = colsum_blocks(M) * N * 4;
+    return slabs > cs ? slabs : cs;
+}
+
+extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M,
+                                int N, int K, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M == 0) return 0;
+    MUMPY_REQUIRE(dy && (dx || dW || db), MUMPY_ENULL, "linear_bwd: null pointer");
+    MUMPY_REQUIRE((!dx || W) && (!dW || x), MUMPY_ENULL, "linear_bwd: dx needs W, dW needs x");
+    MUMPY_REQUIRE(M > 0 && M < (1ll << 31) - 256 && N > 0 && K > 0 && N % 32 == 0 && K % 32 == 0, MUMPY_EINVAL,
+                  "linear_bwd: need N %% 32 == 0 and K %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
+    MUMPY_REQUIRE(aligned16(x) && aligned16(W) && aligned16(dy) && aligned16(dx) && aligned16(dW) && aligned16(db) && aligned16(workspace),
+                  MUMPY_EALIGN, "linear_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE((accumulate & ~3) == 0, MUMPY_EINVAL, "linear_bwd: unknown accumulate bits 0x%x", accumulate);
+    MUMPY_REQUIRE(!workspace || workspace_bytes >= mumpy_linear_bwd_workspace_bytes(M, N, K), MUMPY_EINVAL,
+                  "linear_bwd: workspace too small");
+    MUMPY_REQUIRE(!db || workspace, MUMPY_ENULL, "linear_bwd: db needs the workspace");
+    hipStream_t s = as_stream(stream);
+    float* ws = static_cast<float*>(workspace);
+    if (db) {                                    // first: its partial rows share the workspace with dW's slabs
+        const int64_t nb = colsum_blocks(M);
+        const int rpb = (int)((M + nb - 1) / nb);
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)nb), dim3(256), 0, s, dy, ws, M, N, rpb);
+        MUMPY_CHECK_LAUNCH("linear_bwd(bias partial)");
+        hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, ws, db, (int)nb, N, (accumulate >> 1) & 1);
+        MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
+    }
+    if (dx)          // dX[M,K] = dY[M,N] W[N,K]
+        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, nullptr, 0, s)) return rc;
+    if (dW)          // dW[N,K] (+)= dY^T X
+        if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s)) return rc;
+    return 0;
+}

@@ -1,16 +1,30 @@
 """torch.autograd glue for TRAINING the Swin block on the HIP kernels (first slice: rows 5-7 of 8a).
 
 Every Function's forward and backward is a C-ABI kernel call; torch contributes the tape, the tensors and the shape
-bookkeeping only.  Linear backward reuses the forward GEMM (y = x W^T):
-    dX = dY W      = linear(dY, W^T)           W^T via mumpy_transpose_fwd
-    dW = dY^T X    = linear(dY^T, X^T)         both operands transposed, token dim zero-padded to a multiple of 32
-    db = column sums of dY (fixed-order two-stage reduction)
+bookkeeping only.  Linear backward is one call, mumpy_linear_bwd (csrc/gemm_bwd.hip), on the row-major tensors as they are:
+    dX = dY W,  dW (+)= dY^T X,  db (+)= column sums of dY
+with dW / db accumulated straight into the parameter's `.grad` when that is a view of FlatAdamW's flat gradient buffer.
+(The bf16 operand modes keep the first version's route: the forward GEMM on transposed copies.)
 `swin_block_train(block, x)` runs a `models.modules.swinTransformer.SwinTransformerBlock` through these Functions, with the
 same maths as its inference forward (swin:259-307); in train mode stochastic depth draws a per-sample mask per branch.
 """
+import os
+
 import torch
 
 from . import ops
+
+
+def _grad_slot(p):
+    """The buffer a parameter's gradient is accumulated into by the backward kernels themselves: its `.grad` when that is a
+    dense fp32 tensor of the parameter's shape (FlatAdamW points `.grad` at views of its flat gradient buffer) -- autograd
+    then receives None for it and launches no add."""
+    if p is None or not p.is_leaf:
+        return None
+    g = p.grad
+    if g is not None and g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape and not g.requires_grad:
+        return g
+    return None
 
 
 class LinearFn(torch.autograd.Function):
@@ -18,6 +32,7 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.slots = (_grad_slot(weight), _grad_slot(bias) if bias is not None else None)
         return ops.linear(x, weight, bias)
 
     @staticmethod
@@ -25,10 +40,27 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         n, k = weight.shape
         dy2, x2 = dy.reshape(-1, n).contiguous(), x.reshape(-1, k)
-        dx = ops.linear(dy2, ops.transpose(weight)).reshape(x.shape) if ctx.needs_input_grad[0] else None
-        dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)) if ctx.needs_input_grad[1] else None
-        db = ops.col_sum(dy2) if ctx.has_bias and ctx.needs_input_grad[2] else None
-        return dx, dw, db
+        need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if ops.matrix_math() != "fp32" or LEGACY_LINEAR_BWD:
+            # bf16 operand modes: the forward GEMM on transposed copies (its operand modes apply to the backward products too)
+            dx = ops.linear(dy2, ops.transpose(weight)).reshape(x.shape) if need_dx else None
+            dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)) if need_dw else None
+            db = ops.col_sum(dy2) if need_db else None
+            return dx, dw, db
+        m = dy2.shape[0]
+        wslot, bslot = ctx.slots
+        # large token counts: dX on the forward GEMM (the wave-specialised kernel) against a transposed copy of W -- the
+        # copy is weight-sized and the product runs at 100+ TFLOP/s; everything else in one call, no copies
+        big = need_dx and m >= BIG_DGRAD_ROWS
+        dx, dw, db = ops.linear_bwd(x2.contiguous(), weight, dy2, need_dx=need_dx and not big, need_dw=need_dw, need_db=need_db,
+                                    dw_out=wslot if need_dw else None, db_out=bslot if need_db else None)
+        if big:
+            dx = ops.linear(dy2, ops.transpose(weight))
+        return (dx.reshape(x.shape) if need_dx else None), dw, db
+
+
+LEGACY_LINEAR_BWD = os.environ.get("MUMPY_LEGACY_LINEAR_BWD", "0") != "0"   # the first version's route (transposes + forward GEMM), for A/B runs
+BIG_DGRAD_ROWS = 4096
 
 
 class LayerNormFn(torch.autograd.Function):

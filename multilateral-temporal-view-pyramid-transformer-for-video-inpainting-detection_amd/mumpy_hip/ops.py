@@ -568,6 +568,39 @@ def transpose(x2d, pad_rows_to=1):
     return out
 
 
+def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_dw=True, need_db=False):
+    """Backward of y = x W^T + b in ONE C-ABI call (mumpy_linear_bwd), no transposed copies: -> (dx, dW, db).
+    dw_out / db_out: gradient buffers to ACCUMULATE into (e.g. views of FlatAdamW's flat gradient); the matching return
+    value is then None (nothing left for autograd to add)."""
+    x2d, dy2d, weight = _chk(x2d, "x"), _chk(dy2d, "dy"), _chk(weight, "weight")
+    m, k = x2d.shape
+    n = weight.shape[0]
+    if dy2d.shape != (m, n) or weight.shape[1] != k:
+        raise RuntimeError(f"linear_bwd: x {tuple(x2d.shape)}, weight {tuple(weight.shape)}, dy {tuple(dy2d.shape)} do not match")
+    dev = x2d.device
+    dx = torch.empty(m, k, device=dev, dtype=torch.float32) if need_dx else None
+    acc = 0
+    dw = db = None
+    if need_dw:
+        if dw_out is not None:
+            dw, acc = _chk(dw_out, "dw_out"), acc | 1
+        else:
+            dw = torch.empty(n, k, device=dev, dtype=torch.float32)
+    if need_db:
+        if db_out is not None:
+            db, acc = _chk(db_out, "db_out"), acc | 2
+        else:
+            db = torch.empty(n, device=dev, dtype=torch.float32)
+    key = ("lbwd", m, n, k)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_bwd_workspace_bytes(m, n, k))
+    ws = _ws(wsb, dev)
+    _call("mumpy_linear_bwd", _p(x2d), _p(weight), _p(dy2d), _p(dx), _p(dw), _p(db), m, n, k, acc, _p(ws), wsb, _stream(),
+          work=2.0 * m * n * k * (int(need_dx) + int(need_dw)))
+    return dx, (None if dw_out is not None else dw), (None if db_out is not None else db)
+
+
 def col_sum(x2d):
     x2d = _chk(x2d, "x")
     r, c = x2d.shape

@@ -55,6 +55,51 @@ def test_hip_layernorm_bwd(rows, c):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(392, 768, 3072), (1568, 384, 1536), (50, 96, 96), (6272, 288, 96), (1000, 64, 32), (31360, 384, 128),
+                                   (7840, 2048, 512), (37, 32, 32), (1960, 2304, 768)])
+def test_hip_linear_bwd_one_call(m, n, k):
+    """mumpy_linear_bwd: dX = dY W, dW = dY^T X, db = colsum(dY) from the row-major tensors (no transposed copies; token
+    counts that are no multiple of 32 or of the tile), vs float64 products; accumulate mode adds into existing buffers;
+    split contractions reduce in a fixed order (bitwise reproducible)."""
+    from mumpy_hip import ops
+    x, w, dy = seeded_randn(1, m, k), seeded_randn(2, n, k) / k ** 0.5, seeded_randn(3, m, n)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    dx, dw, db = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=True, need_db=True)
+    ref_dx, ref_dw, ref_db = dy.double() @ w.double(), dy.double().t() @ x.double(), dy.double().sum(0)
+    assert rel_err(dx.cpu(), ref_dx) < 1e-5 and rel_err(dw.cpu(), ref_dw) < 1e-5 and rel_err(db.cpu(), ref_db) < 1e-5
+    dx2, dw2, db2 = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=True, need_db=True)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    gw, gb = seeded_randn(4, n, k).cuda(), seeded_randn(5, n).cuda()
+    gw0, gb0 = gw.clone(), gb.clone()
+    r = ops.linear_bwd(xd, wd, dyd, need_dx=False, need_dw=True, need_db=True, dw_out=gw, db_out=gb)
+    assert r == (None, None, None)
+    assert rel_err(gw.cpu(), gw0.cpu().double() + ref_dw) < 1e-5 and rel_err(gb.cpu(), gb0.cpu().double() + ref_db) < 1e-5
+    only_dx = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=False, need_db=False)
+    assert torch.equal(only_dx[0], dx) and only_dx[1] is None and only_dx[2] is None
+
+
+@pytest.mark.gpu
+def test_hip_linear_fn_accumulates_into_grad_slots():
+    """LinearFn with `.grad` pre-pointed at a buffer (FlatAdamW's layout): the backward kernels add into it and autograd gets
+    None; without a slot the gradients come back as tensors -- both equal torch autograd of F.linear."""
+    from mumpy_hip import autograd as AG
+    x = seeded_randn(1, 2, 196, 96)
+    w, b = (seeded_randn(2, 288, 96) / 96 ** 0.5), seeded_randn(3, 288)
+    g = seeded_randn(4, 2, 196, 288)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.linear(xr, wr, br).backward(g)
+    for slots in (False, True):
+        xd = x.cuda().requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
+        if slots:
+            wd.grad, bd.grad = torch.full_like(wd, 0.5), torch.full_like(bd, -0.25)
+        AG.LinearFn.apply(xd, wd, bd).backward(g.cuda())
+        off_w, off_b = (0.5, -0.25) if slots else (0.0, 0.0)
+        assert rel_err(xd.grad.cpu(), xr.grad) < 2e-5
+        assert rel_err(wd.grad.cpu() - off_w, wr.grad) < 2e-5 and rel_err(bd.grad.cpu() - off_b, br.grad) < 2e-5
+
+
+@pytest.mark.gpu
 def test_hip_gelu_fwd_bwd():
     from mumpy_hip import ops
     x = (seeded_randn(5, 4096) * 3).requires_grad_(True)
