@@ -176,35 +176,50 @@ class GraphedTrainStep:
     Stochastic depth must be off (a captured mask would repeat).  Learning-rate schedules keep working: the AdamW constants
     are staged into device memory before each replay.  Call `step(x, target)` -> loss3 (device tensor [total, iou, focal])."""
 
-    def __init__(self, forward_fn, optimizers, x, target, warmup: int = 3, loss_scale: float = 1.0):
+    def __init__(self, forward_fn, optimizers, x, target, warmup: int = 3, loss_scale: float = 1.0, all_reduce: bool = False):
+        """all_reduce=True (data-parallel ranks): TWO graphs -- forward + loss + backward, and AdamW + gradient reset -- with
+        the bucketed gradient all-reduce (RCCL) issued eagerly between their replays."""
         self.opts = list(optimizers.values()) if isinstance(optimizers, dict) else list(optimizers)
         self.x, self.target = x.clone(), target.clone()
+        self.all_reduce = all_reduce
         for o in self.opts:
             o.enable_device_hyper()
 
-        def body():
+        def fwd_bwd():
             logits = forward_fn(self.x)
             loss3, dlogits = ops.mask_loss(logits.detach(), self.target, loss_scale=loss_scale)
             logits.backward(dlogits)
+            return loss3
+
+        def update():
             for o in self.opts:
                 o.step_dev()
                 o.zero_grad()
-            return loss3
 
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                      # warm-up steps are real steps (caches, allocator, lazy inits)
+                fwd_bwd()
                 for o in self.opts:
-                    o.stage_hyper()
-                body()
+                    o.stage_hyper(o.all_reduce_grads() if all_reduce else 1.0)
+                update()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
         for o in self.opts:
             o.stage_hyper(advance=False)                 # capture records the launches; it does not run a step
-        with torch.cuda.graph(self.graph):
-            self.loss3 = body()
+        self.graph = torch.cuda.CUDAGraph()
+        self.graph_update = None
+        if all_reduce:
+            with torch.cuda.graph(self.graph):
+                self.loss3 = fwd_bwd()
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+                update()
+        else:
+            with torch.cuda.graph(self.graph):
+                self.loss3 = fwd_bwd()
+                update()
         bump_weights_epoch()
 
     def step(self, x=None, target=None, grad_scale: float = 1.0):
@@ -212,8 +227,14 @@ class GraphedTrainStep:
             self.x.copy_(x)
         if target is not None:
             self.target.copy_(target)
-        for o in self.opts:
-            o.stage_hyper(grad_scale)
-        self.graph.replay()
+        if self.graph_update is None:
+            for o in self.opts:
+                o.stage_hyper(grad_scale)
+            self.graph.replay()
+        else:
+            self.graph.replay()
+            for o in self.opts:
+                o.stage_hyper(grad_scale * o.all_reduce_grads())     # the step's collectives, on the replay's stream
+            self.graph_update.replay()
         bump_weights_epoch()
         return self.loss3

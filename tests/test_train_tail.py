@@ -311,9 +311,11 @@ def test_two_rank_training_step_matches_accumulated_single_process():
 
 
 @pytest.mark.gpu
-def test_graphed_train_step_equals_eager_steps():
+@pytest.mark.parametrize("two_graphs", [False, True])
+def test_graphed_train_step_equals_eager_steps(two_graphs):
     """GraphedTrainStep (hipGraph replay of forward + loss + backward + AdamW, step constants staged in device memory) walks the
-    same parameter trajectory as eager steps, learning-rate changes included."""
+    same parameter trajectory as eager steps, learning-rate changes included.  two_graphs: the data-parallel form -- backward
+    and update captured separately, the gradient all-reduce (a no-op at world size 1) issued between the replays."""
     from weight_fill import fill_module_
     from models.decoder.decoder import BaselineDecoder
     from mumpy_hip import ops
@@ -336,7 +338,8 @@ def test_graphed_train_step_equals_eager_steps():
         opt_e.step()
         opt_e.zero_grad()
     dec_g, opt_g = make()
-    gs = GraphedTrainStep(lambda xx: baseline_decoder_train(dec_g, xx), [opt_g], x, target, warmup=3)   # 3 real steps at lrs[0..2]
+    gs = GraphedTrainStep(lambda xx: baseline_decoder_train(dec_g, xx), [opt_g], x, target, warmup=3,
+                          all_reduce=two_graphs)                             # 3 real steps at lrs[0..2]
     for lr in lrs[3:]:
         opt_g.lr = lr
         gs.step()

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--math", choices=["fp32", "bf16", "bf16x3"], default="bf16")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (forward+backward | AdamW), all-reduce eager between them")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
     backend = os.environ.get("MUMPY_BENCH_BACKEND", "nccl")
@@ -55,6 +56,12 @@ def main():
             o.zero_grad()
         return loss3
 
+    if args.graph:
+        from mumpy_hip.train import GraphedTrainStep
+        gs = GraphedTrainStep(lambda xx: decoder_train(dec, *encoder_train(enc, xx))[0], opts, x, target, warmup=max(args.warmup, 2),
+                              all_reduce=world > 1)
+        step = gs.step
+        args.warmup = 1
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -78,7 +85,7 @@ def main():
         same = bool(torch.equal(lo, hi))
     if rank == 0:
         print(json.dumps({"metric": "train clips/s (fwd + loss + bwd + grad all-reduce + AdamW)", "value": round(args.batch * world * args.steps / dt, 3),
-                          "unit": "clips/s", "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "micro_batch": args.batch,
+                          "unit": "clips/s", "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "graph": bool(args.graph), "micro_batch": args.batch,
                           "frames": args.frames, "math": args.math, "backend": backend, "loss": [round(float(v), 5) for v in loss3],
                           "replicas_identical_after_steps": same}))
     if world > 1:
