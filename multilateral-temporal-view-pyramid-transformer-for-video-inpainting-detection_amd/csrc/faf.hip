@@ -22,6 +22,10 @@ namespace {
 constexpr int N = 224;
 constexpr int NCH = N / 32;      // 32-deep K chunks
 constexpr int LDT = 228;         // LDS row stride (dwords): 16-B aligned rows, conflict-free ds_read/write_b128
+#ifndef MUMPY_FAF_WAVES
+#define MUMPY_FAF_WAVES 8
+#endif
+constexpr int NW = MUMPY_FAF_WAVES;   // waves per block: one 32-row tile of a phase each (7 tiles); 4 waves took two tiles each
 
 struct FafArgs {
     const float* L;      // left matrix (224x224, row-major)
@@ -34,7 +38,7 @@ struct FafArgs {
     int lo_hi, mid_lo, mid_hi;
 };
 
-__global__ __launch_bounds__(256) void faf_colblock_kernel(FafArgs a) {
+__global__ __launch_bounds__(64 * NW) void faf_colblock_kernel(FafArgs a) {
     __shared__ __attribute__((aligned(16))) float Rs[32 * LDT];
     __shared__ __attribute__((aligned(16))) float Wt[32 * LDT];
     const int cb = blockIdx.x, plane = blockIdx.y, band = blockIdx.z;
@@ -53,11 +57,11 @@ __global__ __launch_bounds__(256) void faf_colblock_kernel(FafArgs a) {
     }
     const int nch = (kmax + 31) / 32;        // K chunks (phase 1) = row tiles of W that can be non-zero = K chunks of phase 2
 
-    for (int idx = tid; idx < 32 * (N / 4); idx += 256) {                // R[cb rows] -> LDS, 16-B coalesced
+    for (int idx = tid; idx < 32 * (N / 4); idx += 64 * NW) {                // R[cb rows] -> LDS, 16-B coalesced
         const int r = idx / (N / 4), q = idx - r * (N / 4);
         *reinterpret_cast<f32x4*>(&Rs[r * LDT + 4 * q]) = *reinterpret_cast<const f32x4*>(a.R + (int64_t)(cb * 32 + r) * N + 4 * q);
     }
-    for (int idx = tid; idx < 32 * (LDT / 4); idx += 256) *reinterpret_cast<f32x4*>(&Wt[4 * idx]) = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < 32 * (LDT / 4); idx += 64 * NW) *reinterpret_cast<f32x4*>(&Wt[4 * idx]) = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
 
     f32x4 bf[NCH][4];                        // B fragments of the phase: column c of the block, k = 32 ch + 16 h + 4 q ..
@@ -85,8 +89,8 @@ __global__ __launch_bounds__(256) void faf_colblock_kernel(FafArgs a) {
         switch (kc) { FAF_MMA_CHUNK(0) FAF_MMA_CHUNK(1) FAF_MMA_CHUNK(2) FAF_MMA_CHUNK(3) FAF_MMA_CHUNK(4) FAF_MMA_CHUNK(5) FAF_MMA_CHUNK(6) }
 #undef FAF_MMA_CHUNK
     };
-    // phase 1: W[224 x 32] = mask(In) . R[cb]^T; wave w owns row tiles w and w + 4; W goes to LDS transposed
-    for (int t = wave; t < nch; t += 4) {
+    // phase 1: W[224 x 32] = mask(In) . R[cb]^T; wave w owns row tile w (7 tiles, 8 waves); W goes to LDS transposed
+    for (int t = wave; t < nch; t += NW) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -131,7 +135,7 @@ __global__ __launch_bounds__(256) void faf_colblock_kernel(FafArgs a) {
     __syncthreads();
     load_b(Wt);
     // phase 2: Out[:, cb] = L . W   (W is zero past row kmax)
-    for (int t = wave; t < NCH; t += 4) {
+    for (int t = wave; t < NCH; t += NW) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -167,14 +171,14 @@ extern "C" int mumpy_faf_fwd(const float* x, const float* D, const float* Dt, fl
     f.i_batch_stride = (int64_t)T * 3 * P; f.i_plane_stride = P;
     f.o_batch_stride = 3 * P; f.o_plane_stride = P; f.o_band_stride = 0;
     f.masked = 0; f.lo_hi = lo_hi; f.mid_lo = mid_lo; f.mid_hi = mid_hi;
-    hipLaunchKernelGGL(faf_colblock_kernel, dim3(NCH, B * 3, 1), dim3(256), 0, as_stream(stream), f);
+    hipLaunchKernelGGL(faf_colblock_kernel, dim3(NCH, B * 3, 1), dim3(64 * NW), 0, as_stream(stream), f);
     MUMPY_CHECK_LAUNCH("faf(forward)");
     FafArgs g;
     g.L = Dt; g.R = Dt; g.In = scratch; g.Out = out;
     g.i_batch_stride = 3 * P; g.i_plane_stride = P;
     g.o_batch_stride = 9 * P; g.o_plane_stride = P; g.o_band_stride = 3 * P;
     g.masked = 1; g.lo_hi = lo_hi; g.mid_lo = mid_lo; g.mid_hi = mid_hi;
-    hipLaunchKernelGGL(faf_colblock_kernel, dim3(NCH, B * 3, 3), dim3(256), 0, as_stream(stream), g);
+    hipLaunchKernelGGL(faf_colblock_kernel, dim3(NCH, B * 3, 3), dim3(64 * NW), 0, as_stream(stream), g);
     MUMPY_CHECK_LAUNCH("faf(inverse)");
     return 0;
 }
