@@ -25,7 +25,13 @@ class GraphedForward:
         then read freed or recycled memory.  So the capture remembers the weights epoch and __call__ re-captures when it
         has moved (validation between training epochs keeps working; steady-state inference never pays for it)."""
         from . import state
-        side = torch.cuda.Stream(device=self.static_x.device)
+        # warm-up and capture run on the SAME side stream: the per-stream kept workspaces of the GEMMs (ops._kept_workspace)
+        # and the fork/join side streams (keyed by their parent) that the warm-up created are then the ones the captured
+        # launches use -- captured on another stream, every GEMM would record a zero-fill of a fresh 17 MB workspace
+        # (0.86 ms per forward of fill kernels in the first round-2 profile)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.static_x.device)
+        side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():          # warm the derived-table caches off the graph
             for _ in range(self._warmup):
@@ -33,7 +39,7 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph):
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
             self.static_out = self._fwd()
         self.weights_epoch = state.weights_epoch[0]
 

@@ -211,13 +211,13 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_update = None
         if all_reduce:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=side):          # (same stream as the warm-up: see GraphedForward._capture)
                 self.loss3 = fwd_bwd()
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=side):
                 update()
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, stream=side):
                 self.loss3 = fwd_bwd()
                 update()
         bump_weights_epoch()
