@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MUMPY_ABI_VERSION 1
+#define MUMPY_ABI_VERSION 2
 
 #define MUMPY_EINVAL   (-1) /* bad shape / size                              */
 #define MUMPY_EALIGN   (-2) /* pointer not 16-byte aligned where required    */
@@ -265,10 +265,14 @@ int mumpy_adamw_step_dev(float* param, const float* grad, float* exp_avg, float*
 
 /* ---- backward kernels of the Swin block (rows 5-7 of 8a in training) ---------------------------------
  * LayerNorm backward (swin:266,305): x, dy, dx (rows,C); gamma, dgamma, dbeta (C); C % 4 == 0, C <= 2048.
+ * dx_add (rows,C) or null: added to dx -- the gradient arriving over the residual branch that bypasses the LayerNorm
+ * (x feeds both `norm(x)` and `x + ...`, swin:302-305), so the sum needs no separate add kernel.
+ * accumulate = 1: dgamma += / dbeta += (the caller's flat gradient buffer); 0: overwritten.
  * workspace: mumpy_layernorm_bwd_workspace_bytes(rows, C) bytes of device scratch.  Deterministic. */
 int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C);
-int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
-                        void* workspace, int64_t workspace_bytes, int64_t rows, int C, float eps, void* stream);
+int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dx_add, float* dx, float* dgamma,
+                        float* dbeta, void* workspace, int64_t workspace_bytes, int64_t rows, int C, float eps, int accumulate,
+                        void* stream);
 
 /* exact-erf GELU (nn.GELU(), swin:42) as its own kernel for training, where the pre-activation must be kept:
  * y = gelu(x);  dx = dy * gelu'(x).  n % 4 == 0. */

@@ -21,9 +21,9 @@ constexpr int LN_MAXC4 = 8;             // float4 columns per lane: C <= 64 * 4 
 // dependent wave reductions per row), so several independent rows are interleaved
 template <int NC4, int RU>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ dy, float* __restrict__ dx,
-                                                     float* __restrict__ partial, int64_t rows, int C, float eps,
-                                                     int rows_per_wave) {
+                                                     const float* __restrict__ dy, const float* __restrict__ dx_add,
+                                                     float* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C,
+                                                     float eps, int rows_per_wave) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
     const int n4 = C >> 2;                                  // float4 columns
@@ -99,10 +99,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             if (rb + u >= r1) continue;
             const float mg = sg[u] * invc, mgx = sgx[u] * invc, rstd = q[u];
             f32x4* dxr = reinterpret_cast<f32x4*>(dx + (rb + u) * C);
-#pragma unroll
+            const f32x4* dar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + (rb + u) * C) : nullptr;    // gradient of the
+#pragma unroll                                                                                              // residual branch
             for (int i = 0; i < NC4; ++i) {
                 const int c4 = lane + 64 * i;
-                if (c4 < n4) dxr[c4] = (dv[u][i] - mg - xv[u][i] * mgx) * rstd;
+                if (c4 < n4) {
+                    f32x4 g = (dv[u][i] - mg - xv[u][i] * mgx) * rstd;
+                    if (dar) g += dar[c4];
+                    dxr[c4] = g;
+                }
             }
         }
     }
@@ -132,6 +137,27 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
 #pragma unroll
         for (int g = 0; g < 16; ++g) t += red[g][col];
         out[i] = t;
+    }
+}
+
+// LayerNorm backward: partial rows [dgamma(C) | dbeta(C)] per wave -> dgamma, dbeta (the same fixed tree as
+// partial_reduce_kernel), written or ACCUMULATED in place (the caller's gradient buffer: no copies, no add kernels)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int64_t nparts, int C, int accum) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (i < 2 * C)
+        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * 2 * C + i];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        float* o = i < C ? dgamma + i : dbeta + (i - C);
+        *o = accum ? *o + t : t;
     }
 }
 
@@ -374,19 +400,21 @@ extern "C" int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
     return (ln_bwd_waves(rows) + 1) * 2 * C * (int64_t)sizeof(float);      // partial rows + one reduced [dgamma | dbeta] row
 }
 
-extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, float* dx, float* dgamma, float* dbeta,
-                                   void* workspace, int64_t workspace_bytes, int64_t rows, int C, float eps, void* stream) {
+extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dx_add, float* dx,
+                                   float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int64_t rows, int C,
+                                   float eps, int accumulate, void* stream) {
     if (rows == 0) return 0;
     MUMPY_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && workspace, MUMPY_ENULL, "layernorm_bwd: null pointer");
-    MUMPY_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(dy) && aligned16(dx) && aligned16(workspace), MUMPY_EALIGN,
-                  "layernorm_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(dy) && aligned16(dx) && aligned16(dx_add) && aligned16(workspace),
+                  MUMPY_EALIGN, "layernorm_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "layernorm_bwd: accumulate must be 0 or 1");
     MUMPY_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXC4, MUMPY_EINVAL, "layernorm_bwd: unsupported C=%d", C);
     MUMPY_REQUIRE(workspace_bytes >= mumpy_layernorm_bwd_workspace_bytes(rows, C), MUMPY_EINVAL, "layernorm_bwd: workspace too small");
     const int64_t waves = ln_bwd_waves(rows);
     const int rpw = (int)((rows + waves - 1) / waves);
     float* partial = static_cast<float*>(workspace);
 #define MUMPY_LN_BWD(NC4_, RU_)                                                                                     \
-    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx, \
+    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx_add, dx, \
                        partial, rows, C, eps, rpw)
     if (C <= 256) MUMPY_LN_BWD(1, 4);
     else if (C <= 512) MUMPY_LN_BWD(2, 2);
@@ -394,14 +422,9 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
     else MUMPY_LN_BWD(8, 1);
 #undef MUMPY_LN_BWD
     MUMPY_CHECK_LAUNCH("layernorm_bwd");
-    // partial rows are [dgamma(C) | dbeta(C)] per wave: one reduce over width 2C into a scratch row, then two small copies
-    float* both = partial + waves * 2 * C;
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, both,
-                       waves, (int64_t)2 * C, (int64_t)2 * C);
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, dgamma,
+                       dbeta, waves, C, accumulate);
     MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce)");
-    hipError_t e1 = hipMemcpyAsync(dgamma, both, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
-    hipError_t e2 = hipMemcpyAsync(dbeta, both + C, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, as_stream(stream));
-    MUMPY_REQUIRE(e1 == hipSuccess && e2 == hipSuccess, (int)(e1 != hipSuccess ? e1 : e2), "layernorm_bwd: copy of the reduced gradients failed");
     return 0;
 }
 

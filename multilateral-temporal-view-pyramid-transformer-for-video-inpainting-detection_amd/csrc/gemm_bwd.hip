@@ -200,6 +200,27 @@ __global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restri
     }
 }
 
+// short matrices (M <= COLSUM_DIRECT_ROWS): one launch -- 64 columns per block, 16 row lanes each summing every 16th row,
+// combined through LDS in lane order (a fixed tree: bitwise reproducible)
+constexpr int64_t COLSUM_DIRECT_ROWS = 4096;
+__global__ __launch_bounds__(1024) void colsum_direct_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t R, int C,
+                                                             int accum) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int cc = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (cc < C)
+        for (int64_t r = g; r < R; r += 16) s += x[r * C + cc];
+    red[g][col] = s;
+    __syncthreads();
+    if (g == 0 && cc < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][col];
+        out[cc] = accum ? out[cc] + t : t;
+    }
+}
+
 struct XPlan { int wt, ks, cps, nchunks, gr, gc; };
 
 XPlan plan(int R, int C, int KK) {
@@ -258,9 +279,12 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
 extern "C" int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const XPlan p = plan(N, K, (int)M);
-    const int64_t slabs = p.ks > 1 ? (int64_t)p.ks * N * K * 4 : 0;
+    int64_t need = p.ks > 1 ? (int64_t)p.ks * N * K * 4 : 0;                // dW slabs
+    const XPlan q = plan((int)M, K, N);
+    const int64_t dx_slabs = q.ks > 1 ? (int64_t)q.ks * M * K * 4 : 0;      // dX slabs (deep N, few tiles); skipped when huge
+    if (dx_slabs <= (256ll << 20) && dx_slabs > need) need = dx_slabs;
     const int64_t cs = colsum_blocks(M) * N * 4;
-    return slabs > cs ? slabs : cs;
+    return need > cs ? need : cs;
 }
 
 extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M,
@@ -278,7 +302,10 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
     MUMPY_REQUIRE(!db || workspace, MUMPY_ENULL, "linear_bwd: db needs the workspace");
     hipStream_t s = as_stream(stream);
     float* ws = static_cast<float*>(workspace);
-    if (db) {                                    // first: its partial rows share the workspace with dW's slabs
+    if (db && M <= COLSUM_DIRECT_ROWS) {
+        hipLaunchKernelGGL(colsum_direct_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s, dy, db, M, N, (accumulate >> 1) & 1);
+        MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
+    } else if (db) {                             // first: its partial rows share the workspace with dW's slabs
         const int64_t nb = colsum_blocks(M);
         const int rpb = (int)((M + nb - 1) / nb);
         hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)nb), dim3(256), 0, s, dy, ws, M, N, rpb);
@@ -287,7 +314,7 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
         MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
     }
     if (dx)          // dX[M,K] = dY[M,N] W[N,K]
-        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, nullptr, 0, s)) return rc;
+        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s)) return rc;
     if (dW)          // dW[N,K] (+)= dY^T X
         if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s)) return rc;
     return 0;

@@ -68,12 +68,40 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps):
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
+        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
         return ops.layernorm(x, gamma, beta, eps)
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma = ctx.saved_tensors
-        dx, dg, db = ops.layernorm_bwd(x, gamma, dy.contiguous(), ctx.eps)
+        dx, dg, db = _ln_backward(ctx, x, gamma, dy, None)
+        return dx, dg, db, None
+
+
+def _ln_backward(ctx, x, gamma, dy, dx_add):
+    gslot, bslot = ctx.slots
+    both = gslot is not None and bslot is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
+    return ops.layernorm_bwd(x, gamma, dy.contiguous(), ctx.eps, dx_add=None if dx_add is None else dx_add.contiguous(),
+                             dg_out=gslot if both else None, db_out=bslot if both else None)
+
+
+class ResidualLayerNormFn(torch.autograd.Function):
+    """x -> (x, LayerNorm(x)) for the pre-norm residual pattern `x + f(norm(x))` (swin:302-305, blocks:86-92): the gradient that
+    arrives over the residual output is added to the LayerNorm's dx inside the backward kernel (no separate add launch)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        return x.view_as(x), ops.layernorm(x, gamma, beta, eps)
+
+    @staticmethod
+    def backward(ctx, dres, dy):
+        x, gamma = ctx.saved_tensors
+        if dy is None:
+            return dres, None, None, None
+        dx, dg, db = _ln_backward(ctx, x, gamma, dy, dres)
         return dx, dg, db, None
 
 
@@ -153,12 +181,12 @@ def swin_block_train(block, x):
     hs = l // w
     att = block.attn
     tab, ids = att.mask_pack(block.attn_mask)
-    y = LayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    x, y = ResidualLayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
     qkv = LinearFn.apply(y, att.qkv.weight, att.qkv.bias)
     a = WindowAttentionFn.apply(qkv, att.relative_position_bias_table, att.relative_position_index,
                                 (b, hs, w, block.dim, block.shift_size, att.scale), tab, ids)
     x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
-    z = LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
+    x, z = ResidualLayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, block.mlp.fc1.weight, block.mlp.fc1.bias))
     return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, block.mlp.fc2.weight, block.mlp.fc2.bias)))
 
@@ -333,10 +361,10 @@ class TemporalAttentionFn(torch.autograd.Function):
 def global_block_train(block, x):
     """blocks.Block.forward (blocks:77-92) with a backward: x (S, T, C) sites x temporal tokens."""
     att = block.attn.unwrapped
-    y = LayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
+    x, y = ResidualLayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
     a = TemporalAttentionFn.apply(LinearFn.apply(y, att.qkv.weight, att.qkv.bias), att.heads, att.scale)
     x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
-    z = LayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
+    x, z = ResidualLayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     mlp = block.mlp.unwrapped
     hmid = GeluFn.apply(LinearFn.apply(z, mlp.fc1.weight, mlp.fc1.bias))
     return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, mlp.fc2.weight, mlp.fc2.bias)))
@@ -527,7 +555,7 @@ def cross_swin_block_train(blk, x1, x2):
     b, l1, c1 = x1.shape
     hs1 = l1 // w
     att = blk.attn
-    y = LayerNormFn.apply(x1, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
+    x1, y = ResidualLayerNormFn.apply(x1, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps)
     a = WindowAttentionFn.apply(LinearFn.apply(y, att.qkv.weight, att.qkv.bias), att.relative_position_bias_table,
                                 att.relative_position_index, (b, hs1, w, c1, 0, att.scale), None, None)
     out = LinearFn.apply(a, att.proj.weight, att.proj.bias)
@@ -542,7 +570,7 @@ def cross_swin_block_train(blk, x1, x2):
         d = drop_path_train(blk.cva.drop_path, swin_dattention_train(blk.cva.crossattn, x1w, x2w))
         yw = AddFn.apply(x1w, d)                                          # CVAModule: x1 + drop_path(D) (mTVE:138)
         x1 = AddFn.apply(x1, drop_path_train(blk.drop_path, yw.reshape(b, l1, c1)))       # window-major y added to raster x1 (mTVE:285-286)
-    z = LayerNormFn.apply(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
+    x1, z = ResidualLayerNormFn.apply(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
     return AddFn.apply(x1, drop_path_train(blk.drop_path, LinearFn.apply(hmid, blk.mlp.fc2.weight, blk.mlp.fc2.bias))), out
 

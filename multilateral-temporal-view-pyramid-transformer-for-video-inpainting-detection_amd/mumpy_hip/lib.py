@@ -47,7 +47,7 @@ SIGNATURES = {
     "mumpy_mask_loss_workspace_bytes": [c_i, c_l],
     "mumpy_mask_loss_fwd_bwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_fl, c_fl, c_f],
     "mumpy_layernorm_bwd_workspace_bytes": [c_l, c_i],
-    "mumpy_layernorm_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_fl, c_f],
+    "mumpy_layernorm_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_l, c_i, c_fl, c_i, c_f],
     "mumpy_gelu_fwd": [c_f, c_f, c_l, c_f],
     "mumpy_gelu_bwd": [c_f, c_f, c_f, c_l, c_f],
     "mumpy_transpose_fwd": [c_f, c_f, c_l, c_l, c_f],
@@ -72,7 +72,7 @@ SIGNATURES = {
     "mumpy_adamw_step_dev": [c_f, c_f, c_f, c_f, c_l, c_f, c_f],
     "mumpy_adamw_step": [c_f, c_f, c_f, c_f, c_l, c_d, c_d, c_d, c_d, c_d, c_i, c_d, c_f],
 }
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 def library_path() -> str:

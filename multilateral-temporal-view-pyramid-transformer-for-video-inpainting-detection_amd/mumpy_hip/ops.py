@@ -524,19 +524,31 @@ def _ws(nbytes, device):
     return torch.empty(max(nbytes // 4, 4), device=device, dtype=torch.float32)
 
 
-def layernorm_bwd(x, gamma, dy, eps=1e-5):
-    """-> (dx like x, dgamma (C), dbeta (C)) of nn.LayerNorm over the last dim."""
+def layernorm_bwd(x, gamma, dy, eps=1e-5, dx_add=None, dg_out=None, db_out=None):
+    """-> (dx like x, dgamma (C), dbeta (C)) of nn.LayerNorm over the last dim.  dx_add: a gradient to add to dx (the residual
+    branch that bypasses the norm).  dg_out / db_out (both or neither): gradient buffers to ACCUMULATE into; the matching
+    return values are then None."""
     x, dy, gamma = _chk(x, "x"), _chk(dy, "dy"), _chk(gamma, "gamma")
     c = x.shape[-1]
     rows = x.numel() // c
     dx = torch.empty_like(x)
-    dg = torch.empty(c, device=x.device, dtype=torch.float32)
-    db = torch.empty(c, device=x.device, dtype=torch.float32)
-    wsb = int(_lib().mumpy_layernorm_bwd_workspace_bytes(rows, c))
+    if dx_add is not None:
+        dx_add = _chk(dx_add, "dx_add")
+        if dx_add.shape != x.shape:
+            raise RuntimeError("layernorm_bwd: dx_add must have x's shape")
+    if (dg_out is None) != (db_out is None):
+        raise RuntimeError("layernorm_bwd: dg_out and db_out go together")
+    acc = dg_out is not None
+    dg = _chk(dg_out, "dg_out") if acc else torch.empty(c, device=x.device, dtype=torch.float32)
+    db = _chk(db_out, "db_out") if acc else torch.empty(c, device=x.device, dtype=torch.float32)
+    key = ("lnbwd", rows, c)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_layernorm_bwd_workspace_bytes(rows, c))
     ws = _ws(wsb, x.device)
-    _call("mumpy_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dx), _p(dg), _p(db), _p(ws), wsb, rows, c, eps, _stream(),
-          work=12.0 * x.numel())
-    return dx, dg, db
+    _call("mumpy_layernorm_bwd", _p(x), _p(gamma), _p(dy), _p(dx_add), _p(dx), _p(dg), _p(db), _p(ws), wsb, rows, c, eps, int(acc),
+          _stream(), work=12.0 * x.numel())
+    return (dx, None, None) if acc else (dx, dg, db)
 
 
 def gelu(x):

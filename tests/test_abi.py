@@ -37,7 +37,8 @@ def test_library_exports_every_declared_symbol():
             assert len(SIGNATURES[name]) == len(args), f"{name}: binding has {len(SIGNATURES[name])} args, header {len(args)}"
     for name in SIGNATURES:
         assert name in decls, f"{name} bound but not declared in include/mumpy_hip.h"
-    assert lib.mumpy_abi_version() == 1
+    from mumpy_hip.lib import ABI_VERSION
+    assert lib.mumpy_abi_version() == ABI_VERSION == 2          # bumped when mumpy_layernorm_bwd grew dx_add / accumulate
 
 
 def test_binding_argument_types_match_the_header():

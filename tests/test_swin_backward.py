@@ -52,6 +52,13 @@ def test_hip_layernorm_bwd(rows, c):
     assert rel_err(dx.cpu(), x.grad) < 2e-5 and rel_err(dg.cpu(), gm.grad) < 2e-5 and rel_err(db.cpu(), bt.grad) < 2e-5
     dx2, dg2, db2 = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5)
     assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)          # fixed-order reductions
+    # residual-branch gradient folded into dx, parameter gradients accumulated in place (the flat gradient buffer's views)
+    extra = seeded_randn(6, rows, c)
+    gacc, bacc = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -2.0, device="cuda")
+    dx3, r1, r2 = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5, dx_add=extra.cuda(), dg_out=gacc, db_out=bacc)
+    assert r1 is None and r2 is None
+    assert rel_err(dx3.cpu(), x.grad + extra) < 2e-5
+    assert rel_err(gacc.cpu() - 0.5, gm.grad) < 2e-5 and rel_err(bacc.cpu() + 2.0, bt.grad) < 2e-5
 
 
 @pytest.mark.gpu
