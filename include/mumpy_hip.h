@@ -296,6 +296,16 @@ int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M, int N, int K,
                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Weight gradient of mumpy_conv2d_nhwc_fwd (the decoder's nn.Conv2d under loss.backward(), decoder.py:9,24-31,68-95):
+ * dW (Cout,kh,kw,Cin) (+)= sum over output pixels p of dy[p][:] (x) x[p + tap displacement][:], taps outside the image
+ * contributing zero -- ONE launch over all taps on the NHWC tensors as they are (no padded or shifted copies, no transposes):
+ * x (B,H,W,Cin), dy (B,H,W,Cout) NHWC; stride 1, odd taps, zero "same" padding; Cin % 32 == 0, Cout % 32 == 0.
+ * accumulate = 1: dW += (the caller's flat gradient buffer).  Deterministic (pixel ranges split over workgroups into workspace
+ * slabs, reduced in split order).  workspace: mumpy_conv2d_wgrad_workspace_bytes(...) bytes (optional: without it no split). */
+int64_t mumpy_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw);
+int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* dW, int B, int H, int W, int Cin, int Cout, int kh, int kw,
+                            int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* window attention backward (row 5 of 8a in training; swin:145-163 differentiated): qkv (B,Hs*W,3C) and dout (B,Hs*W,C)
  * in raster order as in the forward, bias / mask_tab / mask_id as in the forward, rel_index = the (49*49) int32 image of
  * `relative_position_index`.  Writes dqkv (B,Hs*W,3C) (every element) and dtable (169, C/32) = gradient of

@@ -30,10 +30,15 @@ struct XArgs {
     int ks, chunks_per_split, nchunks;
     int accum;           // ks == 1: out += product
     int gc;              // tiles along C
+    // CONV (weight gradient of a stride-1 "same" convolution, NHWC): contraction index = output pixel p = (img, y, x); the B
+    // row of pixel p for tap (r, s) = blockIdx.z is input pixel p + (r - ph) W + (s - pw) when that is inside the image,
+    // zeros otherwise; the tap's product lands at column offset tap * C of the (Cout, kh, kw, Cin) gradient
+    int cvH, cvW, cv_kw, cv_ph, cv_pw;
+    unsigned cv_mhw, cv_shw, cv_mw, cv_sw;      // p / (H W) and rem / W as mulhi + shift
 };
 
 // WT: wave tile (32 or 64); the workgroup tile is 2 WT x 2 WT (4 waves).  A_T: A's contraction index is the slow one.
-template <int WT, bool A_T>
+template <int WT, bool A_T, bool CONV = false>
 __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
     constexpr int BT = 2 * WT, NB = WT / 32;
     constexpr int LDN = BK + 4;                  // [row][k] image: 36-dword rows (conflict-free ds_read_b128 down the rows)
@@ -50,6 +55,10 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
     const int ch0 = z * a.chunks_per_split;
     int ch1 = ch0 + a.chunks_per_split;
     if (ch1 > a.nchunks) ch1 = a.nchunks;
+    const int tap = CONV ? (int)blockIdx.z : 0;
+    const int tap_r = CONV ? tap / a.cv_kw : 0, tap_s = CONV ? tap - tap_r * a.cv_kw : 0;
+    const int dr = tap_r - a.cv_ph, dc = tap_s - a.cv_pw;
+    const int64_t tap_shift = CONV ? (int64_t)dr * a.cvW + dc : 0;        // pixel displacement of the tap
 
     f32x4 pa[PIECES], pb[PIECES];
     auto fetch = [&](int ch) {
@@ -68,7 +77,13 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
             }
             const int kr = p / (BT / 4), cq = p - kr * (BT / 4);
             const int k = k0 + kr, cc = col0 + 4 * cq;
-            pb[i] = (k < a.KK && cc < a.C) ? *reinterpret_cast<const f32x4*>(a.B + (int64_t)k * a.ldb + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bool ok = k < a.KK && cc < a.C;
+            if (CONV) {
+                const unsigned img = __umulhi((unsigned)k, a.cv_mhw) >> a.cv_shw, rem = (unsigned)k - img * (unsigned)(a.cvH * a.cvW);
+                const unsigned yy = __umulhi(rem, a.cv_mw) >> a.cv_sw, xx = rem - yy * (unsigned)a.cvW;
+                ok = ok && (unsigned)((int)yy + dr) < (unsigned)a.cvH && (unsigned)((int)xx + dc) < (unsigned)a.cvW;
+            }
+            pb[i] = ok ? *reinterpret_cast<const f32x4*>(a.B + ((int64_t)k + tap_shift) * a.ldb + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage = [&]() {
@@ -133,8 +148,8 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
     // wave rows 32 i + rho (A row-major) or 2 rho + i (A contraction-slow), wave columns 2 gamma + j (NB == 2) / gamma
     float* dst;
     int64_t ldd;
-    if (a.ks > 1) { dst = a.slabs + (int64_t)z * a.R * a.C; ldd = a.C; }
-    else { dst = a.out; ldd = a.ldo; }
+    if (a.ks > 1) { dst = a.slabs + ((int64_t)z * gridDim.z + tap) * a.R * a.C; ldd = a.C; }      // [split][tap][R][C]
+    else { dst = a.out + (int64_t)tap * a.C; ldd = a.ldo; }
     const bool accum = a.ks == 1 && a.accum;
 #pragma unroll
     for (int i = 0; i < NB; ++i)
@@ -166,6 +181,22 @@ __global__ __launch_bounds__(256) void xgemm_reduce_kernel(const f32x4* __restri
         for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * n4 + i];
         if (accum) s += out[i];
         out[i] = s;
+    }
+}
+
+// the same for the convolution gradient: slabs [split][tap][R][C] -> out[r][tap * C + c] (row pitch ldo = taps * C)
+__global__ __launch_bounds__(256) void xgemm_reduce_taps_kernel(const f32x4* __restrict__ slabs, float* __restrict__ out, int R, int C,
+                                                                int taps, int ks, int accum) {
+    const int c4n = C / 4;
+    const int64_t per = (int64_t)taps * R * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
+        f32x4 s = slabs[i];
+        for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * per + i];
+        const int64_t t = i / ((int64_t)R * c4n), rc = i - t * R * c4n;
+        const int64_t r = rc / c4n, c4 = rc - r * c4n;
+        f32x4* o = reinterpret_cast<f32x4*>(out + (r * taps + t) * C) + c4;
+        if (accum) s += *o;
+        *o = s;
     }
 }
 
@@ -223,14 +254,14 @@ __global__ __launch_bounds__(1024) void colsum_direct_kernel(const float* __rest
 
 struct XPlan { int wt, ks, cps, nchunks, gr, gc; };
 
-XPlan plan(int R, int C, int KK) {
+XPlan plan(int R, int C, int KK, int taps = 1) {
     XPlan p;
-    const int64_t t128 = (int64_t)((R + 127) / 128) * ((C + 127) / 128);
+    const int64_t t128 = (int64_t)((R + 127) / 128) * ((C + 127) / 128) * taps;
     p.wt = t128 >= 96 ? 64 : 32;                       // wide tiles only when they fill a good part of the chip
     const int bt = 2 * p.wt;
     p.gr = (R + bt - 1) / bt; p.gc = (C + bt - 1) / bt;
     p.nchunks = (KK + BK - 1) / BK;
-    const int64_t tiles = (int64_t)p.gr * p.gc;
+    const int64_t tiles = (int64_t)p.gr * p.gc * taps;
     const int64_t target = p.wt == 64 ? 256 : 768;     // workgroups wanted (2 / 3+ resident per CU)
     int ks = (int)(target / tiles);
     if (ks > p.nchunks / 4) ks = p.nchunks / 4;
@@ -254,6 +285,7 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
     XArgs a;
     a.A = A; a.B = B; a.out = out; a.slabs = ws; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.R = R; a.C = C; a.KK = KK; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accum; a.gc = p.gc;
+    a.cvH = a.cvW = a.cv_kw = a.cv_ph = a.cv_pw = 0; a.cv_mhw = a.cv_shw = a.cv_mw = a.cv_sw = 0;
     const dim3 grid((unsigned)(p.gr * p.gc), (unsigned)p.ks);
     if (p.wt == 64) {
         if (a_t) hipLaunchKernelGGL((xgemm_kernel<64, true>), grid, dim3(256), 0, s, a);
@@ -317,5 +349,54 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
         if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s)) return rc;
     if (dW)          // dW[N,K] (+)= dY^T X
         if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s)) return rc;
+    return 0;
+}
+
+// n / d for every n < 2^31 as mulhi(n, magic) >> shift (round-up method, 31-bit dividends; d >= 2)
+static void magic_div31(unsigned d, unsigned& magic, unsigned& shift) {
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    magic = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
+    shift = s - 1;
+}
+
+extern "C" int64_t mumpy_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return 0;
+    const XPlan p = plan(Cout, Cin, B * H * W, kh * kw);
+    return p.ks > 1 ? (int64_t)p.ks * kh * kw * Cout * Cin * 4 : 0;
+}
+
+extern "C" int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* dW, int B, int H, int W, int Cin, int Cout, int kh,
+                                       int kw, int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    MUMPY_REQUIRE(x && dy && dW, MUMPY_ENULL, "conv2d_wgrad: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dW) && aligned16(workspace), MUMPY_EALIGN,
+                  "conv2d_wgrad: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && H > 0 && W >= 2 && (int64_t)B * H * W < (1ll << 31) - 256, MUMPY_EINVAL, "conv2d_wgrad: bad image batch %dx%dx%d", B, H, W);
+    MUMPY_REQUIRE(kh > 0 && kw > 0 && (kh & 1) && (kw & 1), MUMPY_EINVAL, "conv2d_wgrad: kernel %dx%d must be odd (same padding)", kh, kw);
+    MUMPY_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, MUMPY_EINVAL, "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 32", Cin, Cout);
+    MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "conv2d_wgrad: accumulate must be 0 or 1");
+    const int P = B * H * W, taps = kh * kw;
+    XPlan p = plan(Cout, Cin, P, taps);
+    if (p.ks > 1 && (!workspace || (int64_t)p.ks * taps * Cout * Cin * 4 > workspace_bytes)) { p.ks = 1; p.cps = p.nchunks; }
+    XArgs a;
+    a.A = dy; a.B = x; a.out = dW; a.slabs = static_cast<float*>(workspace);
+    a.lda = Cout; a.ldb = Cin; a.ldo = (int64_t)taps * Cin;
+    a.R = Cout; a.C = Cin; a.KK = P; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accumulate; a.gc = p.gc;
+    a.cvH = H; a.cvW = W; a.cv_kw = kw; a.cv_ph = kh / 2; a.cv_pw = kw / 2;
+    magic_div31((unsigned)(H * W), a.cv_mhw, a.cv_shw);
+    magic_div31((unsigned)W, a.cv_mw, a.cv_sw);
+    hipStream_t s = as_stream(stream);
+    const dim3 grid((unsigned)(p.gr * p.gc), (unsigned)p.ks, (unsigned)taps);
+    if (p.wt == 64) hipLaunchKernelGGL((xgemm_kernel<64, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((xgemm_kernel<32, true, true>), grid, dim3(256), 0, s, a);
+    MUMPY_CHECK_LAUNCH("conv2d_wgrad(product)");
+    if (p.ks > 1) {
+        const int64_t per = (int64_t)taps * Cout * (Cin / 4);
+        int64_t g = (per + 255) / 256;
+        if (g > 2048) g = 2048;
+        hipLaunchKernelGGL(xgemm_reduce_taps_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(workspace), dW,
+                           Cout, Cin, taps, p.ks, accumulate);
+        MUMPY_CHECK_LAUNCH("conv2d_wgrad(reduce)");
+    }
     return 0;
 }

@@ -239,8 +239,8 @@ def baseline_encoder_train(enc, x):
 class Conv2dFn(torch.autograd.Function):
     """3x3 / kxk same-padding convolution on NHWC (mumpy_conv2d_nhwc_fwd).  Backward:
        dX = conv(dY, W flipped and transposed)  (the same implicit-GEMM kernel),
-       dW[tap] = dY^T X_shifted(tap)            (one GEMM per tap over the pixel dimension; the shifted copy of X is a
-                                                 zero-padded slice, i.e. data movement only),
+       dW[tap] = dY^T X_shifted(tap)            (mumpy_conv2d_wgrad_nhwc: ONE launch over all taps on the NHWC tensors as
+                                                 they are, the shift and the zero border are address arithmetic),
        db = column sums of dY."""
 
     @staticmethod
@@ -260,14 +260,17 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_nhwc(dy, w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
         if ctx.needs_input_grad[1]:
-            dyt = ops.transpose(dy2.contiguous(), 32)              # (Cout, Ppad)
-            xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, kw // 2, kw // 2, kh // 2, kh // 2))   # (B,H+2,W+2,Cin)
-            taps = []
-            for ky in range(kh):
-                for kx in range(kw):
-                    xs = xp[:, ky:ky + h, kx:kx + wd, :].reshape(-1, cin).contiguous()
-                    taps.append(ops.linear(dyt, ops.transpose(xs, 32)))                              # (Cout, Cin)
-            dw = torch.stack(taps, dim=1).reshape(cout, kh, kw, cin)
+            if ops.matrix_math() == "fp32" and not LEGACY_LINEAR_BWD:
+                dw = ops.conv2d_wgrad(x, dy, kh, kw)               # one launch over all taps, no shifted copies
+            else:                                                  # bf16 operand modes: one forward GEMM per tap on copies
+                dyt = ops.transpose(dy2.contiguous(), 32)          # (Cout, Ppad)
+                xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, kw // 2, kw // 2, kh // 2, kh // 2))   # (B,H+2,W+2,Cin)
+                taps = []
+                for ky in range(kh):
+                    for kx in range(kw):
+                        xs = xp[:, ky:ky + h, kx:kx + wd, :].reshape(-1, cin).contiguous()
+                        taps.append(ops.linear(dyt, ops.transpose(xs, 32)))                          # (Cout, Cin)
+                dw = torch.stack(taps, dim=1).reshape(cout, kh, kw, cin)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = ops.col_sum(dy2.contiguous())
         return dx, dw, db

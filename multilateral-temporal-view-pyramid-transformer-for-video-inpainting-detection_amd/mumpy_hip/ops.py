@@ -613,6 +613,28 @@ def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_d
     return dx, (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
+def conv2d_wgrad(x, dy, kh, kw, dw_out=None):
+    """Weight gradient of conv2d_nhwc in one launch over all taps: x logical (B,Cin,H,W), dy logical (B,Cout,H,W), both NHWC
+    memory -> dW (Cout,kh,kw,Cin).  dw_out: a buffer to ACCUMULATE into (returns None then)."""
+    x, dy = _nhwc(x, "x"), _nhwc(dy, "dy")
+    b, cin, h, w = x.shape
+    cout = dy.shape[1]
+    if dy.shape != (b, cout, h, w):
+        raise RuntimeError(f"conv2d_wgrad: x {tuple(x.shape)} and dy {tuple(dy.shape)} do not match")
+    acc = dw_out is not None
+    dw = _chk(dw_out, "dw_out") if acc else torch.empty(cout, kh, kw, cin, device=x.device, dtype=torch.float32)
+    if dw.shape != (cout, kh, kw, cin):
+        raise RuntimeError(f"conv2d_wgrad: gradient buffer {tuple(dw.shape)} != {(cout, kh, kw, cin)}")
+    key = ("cwgrad", b, h, w, cin, cout, kh, kw)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_conv2d_wgrad_workspace_bytes(b, h, w, cin, cout, kh, kw))
+    ws = _ws(wsb, x.device) if wsb else None
+    _call("mumpy_conv2d_wgrad_nhwc", _p(x), _p(dy), _p(dw), b, h, w, cin, cout, kh, kw, int(acc), _p(ws), wsb, _stream(),
+          work=2.0 * b * h * w * cout * kh * kw * cin)
+    return None if acc else dw
+
+
 def col_sum(x2d):
     x2d = _chk(x2d, "x")
     r, c = x2d.shape

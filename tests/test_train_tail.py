@@ -8,6 +8,7 @@ import socket
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
@@ -308,6 +309,27 @@ def test_two_rank_training_step_matches_accumulated_single_process():
         swin_block_train(blk, seeded_randn(300 + rank, 2, 196, 96).to(dev)).backward(seeded_randn(310 + rank, 2, 196, 96).to(dev))
     opt.step(grad_scale=0.5)
     assert rel_err(res[0], opt.param.cpu()) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,cin,cout,kh,kw,h,w", [(2, 64, 32, 3, 3, 9, 11), (2, 128, 128, 3, 3, 28, 28), (1, 32, 64, 7, 1, 14, 14),
+                                                  (3, 96, 32, 1, 7, 7, 5), (2, 256, 128, 3, 3, 56, 56), (2, 32, 128, 3, 3, 112, 112)])
+def test_hip_conv2d_wgrad_one_launch(b, cin, cout, kh, kw, h, w):
+    """mumpy_conv2d_wgrad_nhwc (all taps in one launch, borders and shifts by address arithmetic, split pixel ranges reduced in
+    a fixed order) against torch autograd of F.conv2d in float64; accumulate mode adds into an existing buffer."""
+    from mumpy_hip import ops
+    x, dy = seeded_randn(1, b, cin, h, w), seeded_randn(2, b, cout, h, w)
+    wt = torch.zeros(cout, cin, kh, kw, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wt, None, padding=(kh // 2, kw // 2)).backward(dy.double())
+    ref = wt.grad.permute(0, 2, 3, 1)                                   # (Cout, kh, kw, Cin)
+    xd = x.cuda().contiguous(memory_format=torch.channels_last)
+    dyd = dy.cuda().contiguous(memory_format=torch.channels_last)
+    dw = ops.conv2d_wgrad(xd, dyd, kh, kw)
+    assert rel_err(dw.cpu(), ref) < 1e-5
+    assert torch.equal(dw, ops.conv2d_wgrad(xd, dyd, kh, kw))
+    acc = torch.full((cout, kh, kw, cin), 0.25, device="cuda")
+    assert ops.conv2d_wgrad(xd, dyd, kh, kw, dw_out=acc) is None
+    assert rel_err(acc.cpu() - 0.25, ref) < 1e-5
 
 
 @pytest.mark.gpu
