@@ -291,7 +291,9 @@ int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, int64_t works
  * null (skipped).  accumulate bit 0: dW += (else overwritten); bit 1: db += -- the caller's flat gradient buffer, so no
  * separate add kernels.  dx is always overwritten.  N % 32 == 0, K % 32 == 0, M free.  fp32 MFMA, deterministic
  * (deep contractions are split over workgroups into workspace slabs and reduced in split order).
- * workspace: mumpy_linear_bwd_workspace_bytes(M,N,K) bytes of device scratch (required for db; without it dW is not split). */
+ * db costs no launch of its own when dW is computed too (row sums of the dY tiles the dW product stages anyway).
+ * workspace: mumpy_linear_bwd_workspace_bytes(M,N,K) bytes of device scratch (required for db without dW; without it the
+ * products are not split). */
 int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M, int N, int K,
                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);

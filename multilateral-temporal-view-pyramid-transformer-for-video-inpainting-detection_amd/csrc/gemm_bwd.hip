@@ -30,6 +30,11 @@ struct XArgs {
     int ks, chunks_per_split, nchunks;
     int accum;           // ks == 1: out += product
     int gc;              // tiles along C
+    // A_T only: row sums of A over the contraction (= column sums of dY = the bias gradient), computed by the workgroups of
+    // the first column tile from the tiles they stage anyway; null: not wanted
+    float* rowsum;       // [R] (ks == 1) -- or, ks > 1, the partials go to rowsum_slabs [ks][R]
+    float* rowsum_slabs;
+    int rowsum_accum;
     // CONV (weight gradient of a stride-1 "same" convolution, NHWC): contraction index = output pixel p = (img, y, x); the B
     // row of pixel p for tap (r, s) = blockIdx.z is input pixel p + (r - ph) W + (s - pw) when that is inside the image,
     // zeros otherwise; the tap's product lands at column offset tap * C of the (Cout, kh, kw, Cin) gradient
@@ -110,12 +115,18 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
     const float* const a_t = As + 16 * h * LDT + wm * WT + (NB == 2 ? 2 * c : c);     // + t LDT
     const float* const b_t = Bs + 16 * h * LDT + wn * WT + (NB == 2 ? 2 * c : c);
 
+    const bool want_rowsum = A_T && a.rowsum != nullptr && tc == 0 && tap == 0;
+    float rowsum = 0.f;
     if (ch0 < ch1) fetch(ch0);
     for (int ch = ch0; ch < ch1; ++ch) {
         __syncthreads();                         // the previous chunk's fragment reads are done
         stage();
         __syncthreads();
         if (ch + 1 < ch1) fetch(ch + 1);         // global loads fly under this chunk's MFMAs
+        if (A_T && want_rowsum && tid < BT) {
+#pragma unroll 8
+            for (int k = 0; k < BK; ++k) rowsum += As[k * LDT + tid];
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             f32x4 fa[NB];
@@ -144,6 +155,10 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
         }
     }
 
+    if (A_T && want_rowsum && tid < BT && row0 + tid < a.R) {
+        if (a.ks > 1) a.rowsum_slabs[(int64_t)z * a.R + row0 + tid] = rowsum;
+        else a.rowsum[row0 + tid] = a.rowsum_accum ? a.rowsum[row0 + tid] + rowsum : rowsum;
+    }
     // accumulator (i, j)[r] -> row rho = (r&3) + 8 (r>>2) + 4 h, column gamma = c of the 32x32 block; block (i, j) holds
     // wave rows 32 i + rho (A row-major) or 2 rho + i (A contraction-slow), wave columns 2 gamma + j (NB == 2) / gamma
     float* dst;
@@ -174,19 +189,32 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
 }
 
 // out = (accum ? out : 0) + slab[0] + slab[1] + ... in split order (fixed: bitwise reproducible); n4 = R C / 4, dense
+struct RowSumArgs { const float* slabs; float* out; int R, accum; };     // the bias-gradient partials ride in the same launch
+
+__device__ __forceinline__ void reduce_rowsum(const RowSumArgs& rs, int ks) {
+    if (!rs.out) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < rs.R; i += gridDim.x * 256) {
+        float s = rs.slabs[i];
+        for (int z = 1; z < ks; ++z) s += rs.slabs[(int64_t)z * rs.R + i];
+        rs.out[i] = rs.accum ? rs.out[i] + s : s;
+    }
+}
+
 __global__ __launch_bounds__(256) void xgemm_reduce_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ out, int64_t n4,
-                                                           int ks, int accum) {
+                                                           int ks, int accum, RowSumArgs rs) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         f32x4 s = slabs[i];
         for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * n4 + i];
         if (accum) s += out[i];
         out[i] = s;
     }
+    reduce_rowsum(rs, ks);
 }
 
 // the same for the convolution gradient: slabs [split][tap][R][C] -> out[r][tap * C + c] (row pitch ldo = taps * C)
 __global__ __launch_bounds__(256) void xgemm_reduce_taps_kernel(const f32x4* __restrict__ slabs, float* __restrict__ out, int R, int C,
-                                                                int taps, int ks, int accum) {
+                                                                int taps, int ks, int accum, RowSumArgs rs) {
+    reduce_rowsum(rs, ks);
     const int c4n = C / 4;
     const int64_t per = (int64_t)taps * R * c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
@@ -278,11 +306,14 @@ int64_t colsum_blocks(int64_t R) {
     return b < 1 ? 1 : b;
 }
 
+// rowsum (A_T only): also write / accumulate the row sums of A over the contraction (the bias gradient) -- the slab layout
+// is [ks][R][C] followed by [ks][R] row-sum partials
 int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int R, int C, int KK,
-                 int accum, float* ws, int64_t ws_bytes, hipStream_t s) {
+                 int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0) {
     XPlan p = plan(R, C, KK);
-    if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * C * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
+    if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * (C + 1) * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
     XArgs a;
+    a.rowsum = rowsum; a.rowsum_slabs = ws ? ws + (int64_t)p.ks * R * C : nullptr; a.rowsum_accum = rowsum_accum;
     a.A = A; a.B = B; a.out = out; a.slabs = ws; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
     a.R = R; a.C = C; a.KK = KK; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accum; a.gc = p.gc;
     a.cvH = a.cvW = a.cv_kw = a.cv_ph = a.cv_pw = 0; a.cv_mhw = a.cv_shw = a.cv_mw = a.cv_sw = 0;
@@ -299,8 +330,9 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
         const int64_t n4 = (int64_t)R * C / 4;
         int64_t g = (n4 + 255) / 256;
         if (g > 2048) g = 2048;
+        const RowSumArgs rs{a.rowsum_slabs, rowsum, R, rowsum_accum};
         hipLaunchKernelGGL(xgemm_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(ws),
-                           reinterpret_cast<f32x4*>(out), n4, p.ks, accum);
+                           reinterpret_cast<f32x4*>(out), n4, p.ks, accum, rs);
         MUMPY_CHECK_LAUNCH("linear_bwd(reduce)");
     }
     return 0;
@@ -311,7 +343,7 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
 extern "C" int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     const XPlan p = plan(N, K, (int)M);
-    int64_t need = p.ks > 1 ? (int64_t)p.ks * N * K * 4 : 0;                // dW slabs
+    int64_t need = p.ks > 1 ? (int64_t)p.ks * N * (K + 1) * 4 : 0;          // dW slabs + the bias-gradient partials
     const XPlan q = plan((int)M, K, N);
     const int64_t dx_slabs = q.ks > 1 ? (int64_t)q.ks * M * K * 4 : 0;      // dX slabs (deep N, few tiles); skipped when huge
     if (dx_slabs <= (256ll << 20) && dx_slabs > need) need = dx_slabs;
@@ -331,10 +363,13 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
     MUMPY_REQUIRE((accumulate & ~3) == 0, MUMPY_EINVAL, "linear_bwd: unknown accumulate bits 0x%x", accumulate);
     MUMPY_REQUIRE(!workspace || workspace_bytes >= mumpy_linear_bwd_workspace_bytes(M, N, K), MUMPY_EINVAL,
                   "linear_bwd: workspace too small");
-    MUMPY_REQUIRE(!db || workspace, MUMPY_ENULL, "linear_bwd: db needs the workspace");
+    MUMPY_REQUIRE(!db || dW || workspace, MUMPY_ENULL, "linear_bwd: db without dW needs the workspace");
     hipStream_t s = as_stream(stream);
     float* ws = static_cast<float*>(workspace);
-    if (db && M <= COLSUM_DIRECT_ROWS) {
+    // db rides in the dW launch (row sums of dY^T over the tokens, taken from the tiles staged anyway); on its own only
+    // when no dW is wanted
+    if (db && dW) {
+    } else if (db && M <= COLSUM_DIRECT_ROWS) {
         hipLaunchKernelGGL(colsum_direct_kernel, dim3((unsigned)((N + 63) / 64)), dim3(1024), 0, s, dy, db, M, N, (accumulate >> 1) & 1);
         MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
     } else if (db) {                             // first: its partial rows share the workspace with dW's slabs
@@ -348,7 +383,8 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
     if (dx)          // dX[M,K] = dY[M,N] W[N,K]
         if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s)) return rc;
     if (dW)          // dW[N,K] (+)= dY^T X
-        if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s)) return rc;
+        if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s, db,
+                                  (accumulate >> 1) & 1)) return rc;
     return 0;
 }
 
@@ -382,6 +418,7 @@ extern "C" int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* d
     a.A = dy; a.B = x; a.out = dW; a.slabs = static_cast<float*>(workspace);
     a.lda = Cout; a.ldb = Cin; a.ldo = (int64_t)taps * Cin;
     a.R = Cout; a.C = Cin; a.KK = P; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accumulate; a.gc = p.gc;
+    a.rowsum = nullptr; a.rowsum_slabs = nullptr; a.rowsum_accum = 0;
     a.cvH = H; a.cvW = W; a.cv_kw = kw; a.cv_ph = kh / 2; a.cv_pw = kw / 2;
     magic_div31((unsigned)(H * W), a.cv_mhw, a.cv_shw);
     magic_div31((unsigned)W, a.cv_mw, a.cv_sw);
@@ -395,7 +432,7 @@ extern "C" int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* d
         int64_t g = (per + 255) / 256;
         if (g > 2048) g = 2048;
         hipLaunchKernelGGL(xgemm_reduce_taps_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(workspace), dW,
-                           Cout, Cin, taps, p.ks, accumulate);
+                           Cout, Cin, taps, p.ks, accumulate, RowSumArgs{nullptr, nullptr, 0, 0});
         MUMPY_CHECK_LAUNCH("conv2d_wgrad(reduce)");
     }
     return 0;
