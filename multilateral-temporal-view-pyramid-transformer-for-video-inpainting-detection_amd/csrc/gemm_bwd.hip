@@ -290,7 +290,7 @@ XPlan plan(int R, int C, int KK, int taps = 1) {
     p.gr = (R + bt - 1) / bt; p.gc = (C + bt - 1) / bt;
     p.nchunks = (KK + BK - 1) / BK;
     const int64_t tiles = (int64_t)p.gr * p.gc * taps;
-    const int64_t target = p.wt == 64 ? 256 : 768;     // workgroups wanted (2 / 3+ resident per CU)
+    const int64_t target = p.wt == 64 ? 512 : 768;     // workgroups wanted (2 / 3+ resident per CU)
     int ks = (int)(target / tiles);
     if (ks > p.nchunks / 4) ks = p.nchunks / 4;
     if (ks > 64) ks = 64;
