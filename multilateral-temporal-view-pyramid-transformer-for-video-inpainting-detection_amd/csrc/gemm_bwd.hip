@@ -311,7 +311,7 @@ int64_t colsum_blocks(int64_t R) {
 int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int R, int C, int KK,
                  int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0) {
     XPlan p = plan(R, C, KK);
-    if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * (C + 1) * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
+    if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * (C + (rowsum ? 1 : 0)) * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
     XArgs a;
     a.rowsum = rowsum; a.rowsum_slabs = ws ? ws + (int64_t)p.ks * R * C : nullptr; a.rowsum_accum = rowsum_accum;
     a.A = A; a.B = B; a.out = out; a.slabs = ws; a.lda = lda; a.ldb = ldb; a.ldo = ldo;
