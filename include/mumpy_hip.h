@@ -311,13 +311,19 @@ int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* dW, int B, i
 /* window attention backward (row 5 of 8a in training; swin:145-163 differentiated): qkv (B,Hs*W,3C) and dout (B,Hs*W,C)
  * in raster order as in the forward, bias / mask_tab / mask_id as in the forward, rel_index = the (49*49) int32 image of
  * `relative_position_index`.  Writes dqkv (B,Hs*W,3C) (every element) and dtable (169, C/32) = gradient of
- * `relative_position_bias_table`.  P is recomputed from q,k (nothing else is kept from the forward).  Deterministic.
+ * `relative_position_bias_table` (accumulate = 1: dtable +=).  P is recomputed from q,k (nothing else is kept from the
+ * forward).  Deterministic.
  * workspace: mumpy_window_attention_bwd_workspace_bytes(B,Hs,W,C) bytes of device scratch. */
 int64_t mumpy_window_attention_bwd_workspace_bytes(int B, int Hs, int W, int C);
 int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
                                const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv, float* dtable,
                                void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C, int shift, float scale,
-                               void* stream);
+                               int accumulate, void* stream);
+
+/* relative_position_bias_table (169,nH) gathered through relative_position_index (49*49, int32) into the padded bias the
+ * attention kernels read: out (nH,64,64) [head][query][key], rows >= 49 zero, key columns >= 49 = -1e30 (swin:148-151).
+ * One launch (training rebuilds it every step: the table is a parameter). */
+int mumpy_relpos_bias_expand_fwd(const float* table, const int32_t* rel_index, float* out, int nH, void* stream);
 
 /* GroupNorm (+ReLU) backward, NHWC (BaselineDecoder blocks, decoder.py:233-271): z, dy, dz (B,HW,C); stats_partial /
  * nsplit_stats = the partial sums mumpy_gn_stats_nhwc_fwd produced for z; `relu` is the activation that followed the

@@ -891,7 +891,7 @@ __global__ __launch_bounds__(256) void win_attn_dbias_reduce_kernel(const float*
 // dtable[t][head] = sum over the (i, j) pairs with relative_position_index[i][j] == t: one wave per (t, head), lanes
 // stride over the 2401 pairs in order, then a fixed-order wave reduction
 __global__ __launch_bounds__(64) void win_attn_dtable_kernel(const float* __restrict__ full, const int32_t* __restrict__ rel_index,
-                                                             float* __restrict__ dtable, int nH, int ntab) {
+                                                             float* __restrict__ dtable, int nH, int ntab, int accum) {
     const int t = blockIdx.x, head = blockIdx.y, lane = threadIdx.x;
     float s = 0.f;
     for (int p = lane; p < WT * WT; p += 64) {
@@ -899,7 +899,21 @@ __global__ __launch_bounds__(64) void win_attn_dtable_kernel(const float* __rest
         if (rel_index[p] == t) s += full[(int64_t)head * 4096 + i * 64 + j];
     }
     s = wave_sum(s, 64);
-    if (lane == 0) dtable[(int64_t)t * nH + head] = s;
+    if (lane == 0) dtable[(int64_t)t * nH + head] = accum ? dtable[(int64_t)t * nH + head] + s : s;
+}
+
+// relative_position_bias_table (169, nH) + relative_position_index (49*49, int32) -> padded bias (nH, 64, 64) [head][query][key]:
+// rows >= 49 zero, key columns >= 49 = -1e30 (the 49 -> 64 padding mask of the attention kernels; swin:148-151)
+__global__ __launch_bounds__(256) void relpos_bias_expand_kernel(const float* __restrict__ table, const int32_t* __restrict__ rel_index,
+                                                                 float* __restrict__ out, int nH) {
+    const int head = blockIdx.x;
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+        const int i = e >> 6, j = e & 63;
+        float v = 0.f;
+        if (j >= WT) v = -1e30f;
+        else if (i < WT) v = table[(int64_t)rel_index[i * WT + j] * nH + head];
+        out[(int64_t)head * 4096 + e] = v;
+    }
 }
 
 }  // namespace
@@ -990,8 +1004,9 @@ extern "C" int64_t mumpy_window_attention_bwd_workspace_bytes(int B, int Hs, int
 extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
                                           const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv,
                                           float* dtable, void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C,
-                                          int shift, float scale, void* stream) {
+                                          int shift, float scale, int accumulate, void* stream) {
     MUMPY_REQUIRE(qkv && dout && bias && rel_index && dqkv && dtable && workspace, MUMPY_ENULL, "window_attention_bwd: null pointer");
+    MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "window_attention_bwd: accumulate must be 0 or 1");
     MUMPY_REQUIRE((mask_tab == nullptr) == (mask_id == nullptr), MUMPY_ENULL,
                   "window_attention_bwd: mask_tab and mask_id must be given together");
     MUMPY_REQUIRE(aligned16(qkv) && aligned16(dout) && aligned16(bias) && aligned16(mask_tab) && aligned16(dqkv) &&
@@ -1021,8 +1036,16 @@ extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, c
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dbias reduce)");
     const int ntab = (2 * WS - 1) * (2 * WS - 1);
     hipLaunchKernelGGL(win_attn_dtable_kernel, dim3(ntab, a.nH), dim3(64), 0, as_stream(stream), full, rel_index, dtable, a.nH,
-                       ntab);
+                       ntab, accumulate);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dtable)");
+    return 0;
+}
+
+extern "C" int mumpy_relpos_bias_expand_fwd(const float* table, const int32_t* rel_index, float* out, int nH, void* stream) {
+    MUMPY_REQUIRE(table && rel_index && out, MUMPY_ENULL, "relpos_bias_expand: null pointer");
+    MUMPY_REQUIRE(nH > 0, MUMPY_EINVAL, "relpos_bias_expand: bad head count %d", nH);
+    hipLaunchKernelGGL(relpos_bias_expand_kernel, dim3((unsigned)nH), dim3(256), 0, as_stream(stream), table, rel_index, out, nH);
+    MUMPY_CHECK_LAUNCH("relpos_bias_expand");
     return 0;
 }
 

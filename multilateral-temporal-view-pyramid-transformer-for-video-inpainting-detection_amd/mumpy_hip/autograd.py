@@ -160,16 +160,19 @@ class WindowAttentionFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, table, rel_index, dims, mask_tab, mask_id):
         b, hs, w, c, shift, scale = dims
-        bias_pad = ops.expand_relpos_bias(table.detach(), rel_index)
-        ctx.save_for_backward(qkv, bias_pad, rel_index.to(torch.int32).reshape(-1).contiguous())
+        idx32 = ops.rel_index32(rel_index)
+        bias_pad = ops.expand_relpos_bias(table.detach(), idx32)
+        ctx.save_for_backward(qkv, bias_pad, idx32)
         ctx.dims, ctx.mask = dims, (mask_tab, mask_id)
+        ctx.slot = _grad_slot(table)
         return ops.window_attention(qkv, bias_pad, b, hs, w, c, shift, scale, mask_tab, mask_id)
 
     @staticmethod
     def backward(ctx, dout):
         qkv, bias_pad, idx32 = ctx.saved_tensors
         b, hs, w, c, shift, scale = ctx.dims
-        dqkv, dtable = ops.window_attention_bwd(qkv, dout.contiguous(), bias_pad, idx32, b, hs, w, c, shift, scale, *ctx.mask)
+        dqkv, dtable = ops.window_attention_bwd(qkv, dout.contiguous(), bias_pad, idx32, b, hs, w, c, shift, scale, *ctx.mask,
+                                                dtable_out=ctx.slot if ctx.needs_input_grad[1] else None)
         return dqkv, dtable, None, None, None, None
 
 

@@ -310,14 +310,32 @@ def add(a, b, out=None):
     return out
 
 
+_REL_INDEX32 = {}
+
+
+def rel_index32(index: torch.Tensor) -> torch.Tensor:
+    """The (49*49,) int32 image of a `relative_position_index` buffer on its device, cached per buffer (the buffer is a
+    constant of the model: the conversion used to be two launches per W-MSA call of a training step)."""
+    key = (index.data_ptr(), str(index.device), index._version)
+    t = _REL_INDEX32.get(key)
+    if t is None:
+        if len(_REL_INDEX32) > 512:
+            _REL_INDEX32.clear()
+        t = _REL_INDEX32[key] = index.to(torch.int32).reshape(-1).contiguous()
+    return t
+
+
 def expand_relpos_bias(table: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
     """relative_position_bias_table (169,nH) + relative_position_index (49,49) -> (nH,64,64) padded bias
-    [head][query][key]: rows >= 49 zero, key columns >= 49 = -1e30 (swin:148-151)."""
+    [head][query][key]: rows >= 49 zero, key columns >= 49 = -1e30 (swin:148-151).  One launch
+    (mumpy_relpos_bias_expand_fwd)."""
+    table = _chk(table, "table")
     nh = table.shape[1]
-    b = table[index.reshape(-1)].reshape(49, 49, nh).permute(2, 0, 1)
-    out = torch.zeros(nh, 64, 64, device=table.device, dtype=torch.float32)
-    out[:, :, 49:] = NEG
-    out[:, :49, :49] = b
+    if not index.is_cuda:
+        index = index.to(table.device)
+    idx = index if index.dtype == torch.int32 and index.dim() == 1 else rel_index32(index)
+    out = torch.empty(nh, 64, 64, device=table.device, dtype=torch.float32)
+    _call("mumpy_relpos_bias_expand_fwd", _p(table), _p(idx), _p(out), nh, _stream())
     return out
 
 
@@ -645,22 +663,29 @@ def col_sum(x2d):
     return out
 
 
-def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None):
-    """-> (dqkv (B, hs*w, 3C), dtable (169, C/32)): gradients of the W-MSA core wrt qkv and the relative position bias table."""
+def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None, dtable_out=None):
+    """-> (dqkv (B, hs*w, 3C), dtable (169, C/32)): gradients of the W-MSA core wrt qkv and the relative position bias table.
+    dtable_out: a gradient buffer to ACCUMULATE into (the returned dtable is then None)."""
     qkv, dout = _chk(qkv, "qkv"), _chk(dout, "dout")
     if qkv.numel() != b * hs * w * 3 * c or dout.numel() != b * hs * w * c:
         raise RuntimeError("window_attention_bwd: shape mismatch")
     if rel_index32.dtype != torch.int32 or rel_index32.numel() != 49 * 49 or not rel_index32.is_cuda:
         raise RuntimeError("window_attention_bwd: rel_index32 must be the (49*49) int32 relative_position_index on the GPU")
     dqkv = torch.empty_like(qkv)
-    dtable = torch.empty(169, c // 32, device=qkv.device, dtype=torch.float32)
-    wsb = int(_lib().mumpy_window_attention_bwd_workspace_bytes(b, hs, w, c))
+    acc = dtable_out is not None
+    dtable = _chk(dtable_out, "dtable_out") if acc else torch.empty(169, c // 32, device=qkv.device, dtype=torch.float32)
+    if dtable.shape != (169, c // 32):
+        raise RuntimeError(f"window_attention_bwd: table gradient buffer {tuple(dtable.shape)} != {(169, c // 32)}")
+    key = ("wabwd", b, hs, w, c)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_window_attention_bwd_workspace_bytes(b, hs, w, c))
     ws = _ws(wsb, qkv.device)
     n_mask = 0 if mask_id is None else mask_id.numel()
     _call("mumpy_window_attention_bwd", _p(qkv), _p(dout), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
-          _p(rel_index32.contiguous()), _p(dqkv), _p(dtable), _p(ws), wsb, b, hs, w, c, shift, scale, _stream(),
+          _p(rel_index32.contiguous()), _p(dqkv), _p(dtable), _p(ws), wsb, b, hs, w, c, shift, scale, int(acc), _stream(),
           work=5 * 153664.0 * b * (hs // 7) * (w // 7) * (c // 32))
-    return dqkv, dtable
+    return dqkv, (None if acc else dtable)
 
 
 def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, act=ACT_RELU):

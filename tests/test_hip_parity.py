@@ -313,6 +313,21 @@ def test_conv2d_nhwc_b8_wave_specialised_loader(cin, cout, kh, kw, h):
     assert torch.equal(y, y2)                      # fixed-order fix-up of split tiles: bitwise reproducible
 
 
+def test_relpos_bias_expand():
+    """mumpy_relpos_bias_expand_fwd: table[index] scattered into the (nH,64,64) padded bias -- rows >= 49 zero, key columns
+    >= 49 = -1e30 (swin:148-151) -- bit exact against the indexing expression of the reference."""
+    from models.modules.swinTransformer import relative_position_index
+    rpi = relative_position_index(7, 7)
+    for nh in (3, 4, 16, 24):
+        table = seeded_randn(900 + nh, 169, nh)
+        b = ops.expand_relpos_bias(table.to(DEV), rpi.to(DEV)).cpu()
+        assert b.shape == (nh, 64, 64)
+        ref = table[rpi.reshape(-1)].reshape(49, 49, nh).permute(2, 0, 1)
+        assert torch.equal(b[:, :49, :49], ref)
+        assert bool((b[:, :, 49:] == -1e30).all()) and bool((b[:, 49:, :49] == 0).all())
+        assert torch.equal(b, ops.expand_relpos_bias(table.to(DEV), ops.rel_index32(rpi.to(DEV))).cpu())
+
+
 def test_linear_rows_strided_time_slices():
     """One time slice of (B, T, n, C) tokens as a (B*n, C) GEMM operand without a copy, chained via the residual."""
     b, t, n, c, nout = 3, 5, 196, 128, 256
