@@ -65,8 +65,10 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
     const int dr = tap_r - a.cv_ph, dc = tap_s - a.cv_pw;
     const int64_t tap_shift = CONV ? (int64_t)dr * a.cvW + dc : 0;        // pixel displacement of the tap
 
-    f32x4 pa[PIECES], pb[PIECES];
-    auto fetch = [&](int ch) {
+    // global -> register staging runs TWO chunks ahead of the MFMAs (two register sets, 4-8 f32x4 each): with 16-64 MFMAs per
+    // chunk and wave, one chunk of lead does not cover a memory round trip on the short launches
+    f32x4 pa0[PIECES], pb0[PIECES], pa1[PIECES], pb1[PIECES];
+    auto fetch = [&](int ch, f32x4 (&pa)[PIECES], f32x4 (&pb)[PIECES]) {
         const int k0 = ch * BK;
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
             pb[i] = ok ? *reinterpret_cast<const f32x4*>(a.B + ((int64_t)k + tap_shift) * a.ldb + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto stage = [&]() {
+    auto stage = [&](const f32x4 (&pa)[PIECES], const f32x4 (&pb)[PIECES]) {
 #pragma unroll
         for (int i = 0; i < PIECES; ++i) {
             const int p = tid + 256 * i;
@@ -117,12 +119,7 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
 
     const bool want_rowsum = A_T && a.rowsum != nullptr && tc == 0 && tap == 0;
     float rowsum = 0.f;
-    if (ch0 < ch1) fetch(ch0);
-    for (int ch = ch0; ch < ch1; ++ch) {
-        __syncthreads();                         // the previous chunk's fragment reads are done
-        stage();
-        __syncthreads();
-        if (ch + 1 < ch1) fetch(ch + 1);         // global loads fly under this chunk's MFMAs
+    auto compute = [&]() {
         if (A_T && want_rowsum && tid < BT) {
 #pragma unroll 8
             for (int k = 0; k < BK; ++k) rowsum += As[k * LDT + tid];
@@ -152,6 +149,22 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
             }
+        }
+    };
+    if (ch0 < ch1) fetch(ch0, pa0, pb0);
+    if (ch0 + 1 < ch1) fetch(ch0 + 1, pa1, pb1);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        __syncthreads();                         // the previous chunk's fragment reads are done
+        stage(pa0, pb0);
+        __syncthreads();
+        if (ch + 2 < ch1) fetch(ch + 2, pa0, pb0);
+        compute();
+        if (ch + 1 < ch1) {
+            __syncthreads();
+            stage(pa1, pb1);
+            __syncthreads();
+            if (ch + 3 < ch1) fetch(ch + 3, pa1, pb1);
+            compute();
         }
     }
 
