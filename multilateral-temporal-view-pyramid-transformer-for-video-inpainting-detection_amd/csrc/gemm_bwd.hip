@@ -12,6 +12,10 @@
 // rows of the wave's 64 -- the output row (column) permutation is undone by the store addresses, nothing is transposed.
 // dW / db can be accumulated into (the caller's flat gradient buffer: no separate add kernels), deep contractions are
 // split over workgroups with per-split slabs and a fixed-order reduce (bitwise reproducible).  fp32 MFMA, exact products.
+// db costs no launch: the workgroups of the first column tile of the dW product sum the dY tiles they stage anyway.
+// The same kernel with the tap as a grid dimension is the weight gradient of the decoder's convolutions
+// (mumpy_conv2d_wgrad_nhwc: contraction over output pixels, the B row of pixel p for tap (r, s) is input pixel
+// p + (r - ph) W + (s - pw) or zeros -- decided per staged 16-byte piece by two magic-number divisions; decoder.py:9,24-31).
 #include "common.h"
 using namespace mumpy;
 
