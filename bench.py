@@ -59,6 +59,9 @@ def parse():
                     help="matrix arithmetic of the GEMMs/convolutions: fp32 on the fp32 MFMA (headline, default), bf16x3 = fp32 "
                          "products from three bf16 pieces per operand on the bf16 MFMA (fp32-level accuracy), bf16 = bf16 "
                          "operands + fp32 accumulate")
+    ap.add_argument("--storage", choices=["fp32", "bf16"], default="fp32",
+                    help="bf16: BASELINE config 3 as written (bf16 activations / weights in HBM inside the Swin blocks, bf16 MFMA, "
+                         "f32 accumulate / statistics / residual stream); never the headline configuration")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement reported beside the fp32 headline")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,6 +295,9 @@ def main():
     from weight_fill import fill_module_, seeded_randn
 
     ops.set_matrix_math(args.math)
+    if args.storage == "bf16":
+        ops.set_storage("bf16")                   # (implies the bf16 matrix-math mode for the GEMMs outside the Swin blocks)
+        args.math = "bf16s"
     log("building model + synthetic weights")
     enc = fill_module_(Encoder(num_frames=args.frames).eval()).to(dev)
     dec = fill_module_(Decoder(input_token_temporal_dims=[1, 1, args.frames]).eval()).to(dev)
@@ -358,9 +364,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16x3": "f32 (matrix products from 3 bf16 pieces per operand on the bf16 MFMA, f32 accumulate)",
                       "bf16x2": "matrix operands as 2 bf16 pieces (16 mantissa bits, TF32-class), f32 accumulate and storage",
-                      "bf16": "bf16 matrix operands, f32 accumulate and storage"}[args.math], "data": "synthetic",
+                      "bf16": "bf16 matrix operands, f32 accumulate and storage",
+                      "bf16s": "bf16 activations / weights in HBM and bf16 MFMA operands inside the Swin blocks; f32 accumulate, statistics "
+                               "and residual stream (config 3)"}[args.math], "data": "synthetic",
             "config": {"workload": f"full Mumpy forward (3 temporal views, pyramid decoder), B={args.batch} clips/GPU, "
-                                   f"T={args.frames}, 224x224, fp32, tubelets ({args.frames},{args.frames - 1},1)",
+                                   f"T={args.frames}, 224x224, {'bf16 storage' if args.math == 'bf16s' else 'fp32'}, "
+                                   f"tubelets ({args.frames},{args.frames - 1},1)",
                        "global_batch": args.batch * world, "launch": ("eager" if fwd is None else "hipGraph replay") + ", fork/join over HIP streams (independent branches co-scheduled)",
                        "parallelism": f"batch-sharded x{world}, one metric all-reduce"},
             "roofline": dom,
