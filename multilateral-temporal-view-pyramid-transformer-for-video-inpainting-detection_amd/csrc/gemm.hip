@@ -904,6 +904,25 @@ extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float*
     float* yf = static_cast<float*>(y);
     const ConvGeom cg{0, 0, 0, 0, 0, 0, 0};
     hipStream_t s = as_stream(stream);
+    MUMPY_REQUIRE(!(out_bf16 && residual), MUMPY_EINVAL, "linear_bf16s: a bf16 output takes no residual");
+    // large shapes: the persistent wave-specialised kernel with bf16 stages (gemm_ws.h; MUMPY_GEMM_WS16=0 disables it)
+    {
+        static const int ws16 = getenv("MUMPY_GEMM_WS16") ? atoi(getenv("MUMPY_GEMM_WS16")) : 1;
+        static int num_cu = 0;
+        if (!num_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+            else num_cu = NUM_CU;
+        }
+        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        const double rounds = (double)tiles / num_cu, eff = rounds / (double)((tiles + num_cu - 1) / num_cu);
+        if (ws16 && gemm_ws::eligible16(M, N, K) && (ws16 == 2 || (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.75))) {
+            if (int rc = gemm_ws::launch16(x, W, bias, residual, y, M, N, K, act, out_bf16 != 0, num_cu, s)) return rc;
+            MUMPY_CHECK_LAUNCH("linear_bf16s(ws)");
+            return 0;
+        }
+    }
     const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
     const unsigned gn128 = (N + 127) / 128, gn64 = (N + 63) / 64;
     // the products take 1/16 of the fp32 MFMA time: these launches are staging-bound, so prefer the wide tile (half the

@@ -30,6 +30,10 @@
 // K=128 +GELU 155 us [215]; M=1960 N=3072 K=768 (1.5 rounds of tiles, split) 93 us [104].  Matrix waves alone 116-120.
 // LDS: 3 stages x 256 rows x 32 dwords, XOR-swizzled 16-B chunks (98,304 B) + the 128x128 accumulator image (65,536 B)
 // = 163,840 B, the whole CU.
+// The same skeleton runs the decoder's convolutions (loader_role<CONV>: implicit GEMM, taps by address arithmetic) and
+// config 3's bf16-storage GEMMs (IO = 1 / 2: bf16 stages -- a 128-byte tile row is 64 bf16 -- on
+// v_mfma_f32_32x32x16_bf16, bf16 or fp32 output): M=7840 N=512 K=2048 24.8 us [tiled bf16 kernel 65.2], N=2048 K=512 +GELU
+// 33.0 [43.4], N=512 K=512 11.6 [35.7]; with 512 matrix-pipe cycles per chunk those are bound by the epilogue waves.
 #pragma once
 #include "common.h"
 
@@ -237,6 +241,72 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int kc0
     ws_barrier();                                   // the last tile's accumulators are in LDS
 }
 
+// bf16 operands (config 3's storage): the same stage image -- a tile row is 128 bytes = 64 bf16, so a chunk is 64 deep --
+// and v_mfma_f32_32x32x16_bf16: lane (c, h) supplies k = 8 h .. 8 h + 7 of a 16-deep step, i.e. the 16-byte chunk 2 t + h of
+// its row for step t: one ds_read_b128 per operand and MFMA, 16 MFMAs (512 matrix-pipe cycles) per chunk and wave.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void matrix_role16(const Params& p, float* lds, int kc0, int n_chunks, int wave, int lane) {
+    const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int sw = (c >> 1) & 7;
+    int a_off[4], b_off[4];                          // dword offsets of this lane's chunk (2 t + h) in tile row c
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        a_off[t] = (64 * wm + c) * BK + 4 * ((2 * t + h) ^ sw);
+        b_off[t] = (BM + 64 * wn + c) * BK + 4 * ((2 * t + h) ^ sw);
+    }
+    float* const E = lds + E_OFF_DW + (64 * wm + 4 * h) * BN + 64 * wn + c;
+    f32x16 acc[2][2];
+    bf16x8 fa0[2], fb0[2], fa1[2], fb1[2];
+    auto rd = [&](const float* st, int t, bf16x8 (&fa)[2], bf16x8 (&fb)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(st + a_off[t] + 32 * i * BK);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(st + b_off[t] + 32 * j * BK);
+    };
+    auto mm_row = [&](const bf16x8 (&fa)[2], const bf16x8 (&fb)[2], int i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    auto dump = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) E[(32 * i + (r & 3) + 8 * (r >> 2)) * BN + 32 * j] = acc[i][j][r];
+    };
+    auto zero = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero();
+    ws_barrier();                                   // chunk 0 is staged
+    rd(lds, 0, fa0, fb0);
+    int kc = kc0, stage = 0;
+    for (int i = 0; i < n_chunks; ++i) {
+        const float* st = lds + stage * STAGE_DW;
+        stage = stage == NSTAGE - 1 ? 0 : stage + 1;
+        if (kc == 0 && i > 0) { dump(); zero(); }
+        rd(st, 1, fa1, fb1);
+        mm_row(fa0, fb0, 0); mm_row(fa0, fb0, 1);
+        rd(st, 2, fa0, fb0);
+        mm_row(fa1, fb1, 0); mm_row(fa1, fb1, 1);
+        rd(st, 3, fa1, fb1);
+        mm_row(fa0, fb0, 0); mm_row(fa0, fb0, 1);
+        mm_row(fa1, fb1, 0);
+        ws_barrier();                               // chunk i+1 is staged
+        rd(lds + stage * STAGE_DW, 0, fa0, fb0);    // (after the last chunk: a harmless read of an idle stage)
+        mm_row(fa1, fb1, 1);
+        if (++kc == p.nk) kc = 0;
+    }
+    dump();
+    ws_barrier();                                   // the last tile's accumulators are in LDS
+}
+
 // ------------------------------------------------------------------------------------------------ loader waves
 // Waves 4-7: operand chunks by LDS-DMA (buffer_load ... lds, 16 B per lane; a wave-instruction fills 8 tile rows), three
 // stages: at iteration i the DMA of chunk i+2 goes into the stage chunk i-1 vacated, and the wave then waits -- counted,
@@ -251,8 +321,9 @@ __device__ __forceinline__ void matrix_role(const Params& p, float* lds, int kc0
 // decodes its four rows once (two magic-number divisions) and keeps a bit mask of the taps that fall inside the image;
 // per chunk that is one bit test, one add of the chunk's (wave-uniform) byte displacement and one select of the OOB offset
 // per piece: out-of-image taps are dropped by the buffer range check and the DMA writes zeros.
-template <bool CONV>
+template <bool CONV, bool IN16 = false>
 __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigned tile0, int kc0, int n_chunks, int hl) {
+    constexpr uint32_t ESZ = IN16 ? 2u : 4u;                     // operand element size: a tile row is 128 bytes either way
     const int lane = hl & 63, lw = __builtin_amdgcn_readfirstlane(hl >> 6);
     const int prow = lane >> 3;                                  // row inside a piece
     uint32_t aoff[4], boff[4];                                   // byte offsets of this lane's source chunk, per piece
@@ -278,11 +349,11 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
                 amask[q] = mask;
                 aoff[q] = ((uint32_t)m * (uint32_t)p.cv_C + 4u * ch) * 4u;
             } else {
-                aoff[q] = ((uint32_t)m * (uint32_t)p.K + 4u * ch) * 4u;
+                aoff[q] = (uint32_t)m * (uint32_t)p.K * ESZ + 16u * ch;
             }
             int n = (int)tn * BN + r;
             if (n > p.N - 1) n = p.N - 1;
-            boff[q] = ((uint32_t)n * (uint32_t)p.K + 4u * ch) * 4u;
+            boff[q] = (uint32_t)n * (uint32_t)p.K * ESZ + 16u * ch;
         }
     };
     const auto rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)0x7fffffff, 0x00020000);
@@ -372,13 +443,15 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
 // (P >= ceil(16 / (nk - 1))): bias, exact-erf GELU, residual, one 16-B store per lane -- ~60 vector instructions per
 // GELU pass, which fit the issue slots the MFMA stream leaves.  The pass code is unrolled with static register indices;
 // the chunks that remain of a tile only join the barrier.
-template <int P>
+// OUT16: y is bf16 (config 3's activation storage; no residual then): a pass packs its four values and stores 8 bytes.
+template <int P, bool OUT16 = false>
 __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned b, unsigned G, unsigned u0, unsigned u1, int hl) {
+    constexpr uint32_t OSZ = OUT16 ? 2u : 4u;
     const float* const E = lds + E_OFF_DW;
     const int e_row = hl >> 5, e_c4 = hl & 31;
     const unsigned nk = (unsigned)p.nk;
     const bool split = p.flags != nullptr;
-    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.M * p.N * 4), 0x00020000);
+    const auto rs_y = __builtin_amdgcn_make_buffer_rsrc(p.Y, 0, (int)((int64_t)p.M * p.N * OSZ), 0x00020000);
     const auto rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.residual ? p.residual : p.Y), 0,
                                                         p.residual ? (int)((int64_t)p.M * p.N * 4) : 0, 0x00020000);
     const auto rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bias ? p.bias : p.Y), 0, p.bias ? p.N * 4 : 0, 0x00020000);
@@ -387,14 +460,14 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
     constexpr int STEPS = PASSES / P;
     f32x4 rv[PASSES], bias4;
     uint32_t yo[PASSES];                            // byte offsets of this lane's 16 output rows in y (tile in flight)
-    const uint32_t row8 = 8u * (uint32_t)p.N * 4u;  // byte pitch of 8 rows of y
+    const uint32_t row8 = 8u * (uint32_t)p.N * OSZ; // byte pitch of 8 rows of y
     // Rows past M need no predicate: their offsets are past the end of the buffer (num_records = M N 4) and the access is
     // dropped by the range check; columns past N start from the OOB offset.
     auto begin_tile = [&](unsigned t) {             // the tile whose image is being dumped: fetch its residual rows + bias
         unsigned tm, tn;
         tile_coords(p, t, tm, tn);
         const int n = (int)tn * BN + 4 * e_c4;
-        const uint32_t ybase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * 4u : OOB;
+        const uint32_t ybase = n < p.N ? (((uint32_t)tm * BM + e_row) * (uint32_t)p.N + (uint32_t)n) * OSZ : OOB;
 #pragma unroll
         for (int e = 0; e < PASSES; ++e) {
             yo[e] = ybase + (uint32_t)e * row8;
@@ -409,7 +482,14 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
             for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
         }
         v += rv[e];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, yo[e], 0, 0);
+        if (OUT16) {
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // round to nearest even
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, yo[e], 0, 0);
+        } else {
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, yo[e], 0, 0);
+        }
     };
     const uint32_t soff = ((uint32_t)e_row * BN + 4u * e_c4) * 4u;
     auto pass_part = [&](int e) {                   // raw partial sums -> this workgroup's slab (always in range)
@@ -525,7 +605,8 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
     }
 }
 
-template <int P, bool CONV = false>
+// IO: 0 = fp32 operands and output; 1 = bf16 operands, bf16 output; 2 = bf16 operands, fp32 output (+ fp32 residual)
+template <int P, bool CONV = false, int IO = 0>
 __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -548,13 +629,15 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     if (n_chunks == 0) return;
     const unsigned t0 = u0 / (unsigned)p.nk;
     const int kc0 = (int)(u0 - t0 * (unsigned)p.nk);
-    if (wave < 4) matrix_role(p, lds, kc0, n_chunks, wave, lane);
-    else {
+    if (wave < 4) {
+        if (IO == 0) matrix_role(p, lds, kc0, n_chunks, wave, lane);
+        else matrix_role16(p, lds, kc0, n_chunks, wave, lane);
+    } else {
         // (priority: no measurable effect either way beside an fp32 MFMA stream -- tools/micro/coissue.hip; kept so that
         // the few instructions of these roles are not additionally delayed by arbitration)
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(3);
-        if (wave < 8) loader_role<CONV>(p, lds, t0, kc0, n_chunks, tid - 256);
-        else epilogue_role<P>(p, lds, b, G, u0, u1, tid - 512);
+        if (wave < 8) loader_role<CONV, IO != 0>(p, lds, t0, kc0, n_chunks, tid - 256);
+        else epilogue_role<P, IO == 1>(p, lds, b, G, u0, u1, tid - 512);
     }
 }
 
@@ -654,6 +737,60 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     else if (P == 4) MUMPY_WS_LAUNCH(4);
     else MUMPY_WS_LAUNCH(8);
 #undef MUMPY_WS_LAUNCH
+    return 0;
+}
+
+// ---- bf16 operands (config 3's storage).  x (M,K) and W (N,K) bf16 in memory, bias / residual fp32, y bf16 (no residual)
+// or fp32.  Whole tiles only (these launches are short: no slab round trip).  A chunk is 64 deep.
+inline bool eligible16(int64_t M, int N, int K) {
+    return K % 64 == 0 && K >= 192 && N % 4 == 0 && M >= 1 && M * (int64_t)K * 2 < (1ll << 31) && (int64_t)N * K * 2 < (1ll << 31) &&
+           M * (int64_t)N * 4 < (1ll << 31);
+}
+
+inline int launch16(const void* x16, const void* W16, const float* bias, const float* residual, void* y, int64_t M, int N, int K,
+                    int act, bool out_bf16, int num_cu, hipStream_t s) {
+    Params p;
+    p.cv_H = p.cv_W = p.cv_C = p.cv_kh = p.cv_kw = p.cv_cpc = 0;
+    p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
+    p.X = static_cast<const float*>(x16); p.W = static_cast<const float*>(W16); p.bias = bias; p.residual = residual;
+    p.Y = static_cast<float*>(y);
+    p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / 64;
+    p.gm = (unsigned)((M + BM - 1) / BM); p.gn = (unsigned)((N + BN - 1) / BN);
+    p.tiles = p.gm * p.gn;
+    p.units = p.tiles * (unsigned)p.nk;
+#ifdef MUMPY_WS_STAMP
+    p.stamps = nullptr;
+#endif
+    const int need = (PASSES + p.nk - 2) / (p.nk - 1);
+    const int P = need <= 1 ? 1 : need <= 2 ? 2 : need <= 4 ? 4 : 8;
+    p.lmin = 1 + PASSES / P;
+    const unsigned grid = p.tiles < (unsigned)num_cu ? p.tiles : (unsigned)num_cu;
+    p.st_w = (p.gn % 4 == 0) ? 4u : (p.gn % 2 == 0) ? 2u : 1u;
+    p.rr_G = grid;
+    p.rr_cnt = (p.tiles + grid - 1) / grid;
+    p.flags = nullptr; p.slabs = nullptr;
+#define MUMPY_WS_LAUNCH16(P_, IO_)                                                                                      \
+    do {                                                                                                                \
+        static bool attr_set = false;                                                                                   \
+        if (!attr_set) {                                                                                                \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<P_, false, IO_>),           \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
+            if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
+            attr_set = true;                                                                                            \
+        }                                                                                                               \
+        hipLaunchKernelGGL((gemm_ws_kernel<P_, false, IO_>), dim3(grid), dim3(768), LDS_BYTES, s, p);                   \
+    } while (0)
+#define MUMPY_WS_PICK16(IO_)                                                                                            \
+    do {                                                                                                                \
+        if (P == 1) MUMPY_WS_LAUNCH16(1, IO_);                                                                          \
+        else if (P == 2) MUMPY_WS_LAUNCH16(2, IO_);                                                                     \
+        else if (P == 4) MUMPY_WS_LAUNCH16(4, IO_);                                                                     \
+        else MUMPY_WS_LAUNCH16(8, IO_);                                                                                 \
+    } while (0)
+    if (out_bf16) MUMPY_WS_PICK16(1);
+    else MUMPY_WS_PICK16(2);
+#undef MUMPY_WS_PICK16
+#undef MUMPY_WS_LAUNCH16
     return 0;
 }
 

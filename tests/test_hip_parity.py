@@ -917,8 +917,11 @@ def _bf16(t):
 def test_linear_bf16_storage():
     """mumpy_linear_bf16s_fwd: bf16 x and W in memory, fp32 accumulate -- against an fp64 product of the SAME bf16 operands
     (so only the accumulation order and the output rounding differ): fp32 output to 2e-5, bf16 output to one bf16 ulp."""
+    # (7840, 512, 512), (7840, 2048, 512) and (31360, 256, 1024) run on the persistent wave-specialised kernel with bf16 stages
+    # (>= 0.75 of a round of 128x128 tiles, K % 64 == 0, K >= 192), the ragged M = 7800 one through its edge predication
     for (m, n, k, act, res) in [(200, 96, 64, 0, True), (7840, 512, 512, 0, True), (1568, 1536, 384, 1, False), (392, 768, 3072, 0, True),
-                                (6272, 192, 96, 1, False)]:
+                                (6272, 192, 96, 1, False), (7840, 2048, 512, 1, False), (31360, 256, 1024, 0, True),
+                                (7800, 1504, 192, 1, False)]:
         x = _bf16(seeded_randn(m + n, m, k)).to(DEV)
         w = _bf16(seeded_randn(m + n + 1, n, k) / k ** 0.5).to(DEV)
         b = seeded_randn(m + n + 2, n).to(DEV)
