@@ -905,9 +905,12 @@ extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float*
     const ConvGeom cg{0, 0, 0, 0, 0, 0, 0};
     hipStream_t s = as_stream(stream);
     MUMPY_REQUIRE(!(out_bf16 && residual), MUMPY_EINVAL, "linear_bf16s: a bf16 output takes no residual");
-    // large shapes: the persistent wave-specialised kernel with bf16 stages (gemm_ws.h; MUMPY_GEMM_WS16=0 disables it)
+    // every eligible shape (K % 64 == 0, K >= 192): the persistent wave-specialised kernel with bf16 stages (gemm_ws.h).  With
+    // 512 matrix-pipe cycles per chunk even a launch of 40 tiles is latency-bound, and the DMA pipeline of that kernel beats
+    // the tiled kernel's load -> convert -> LDS loop everywhere (forward of config 3: 725 -> 797 clips/s against taking it
+    // only for >= 0.75 of a round of tiles).  MUMPY_GEMM_WS16=0 disables it, =1 restricts it to the large shapes (A/B runs).
     {
-        static const int ws16 = getenv("MUMPY_GEMM_WS16") ? atoi(getenv("MUMPY_GEMM_WS16")) : 1;
+        static const int ws16 = getenv("MUMPY_GEMM_WS16") ? atoi(getenv("MUMPY_GEMM_WS16")) : 2;
         static int num_cu = 0;
         if (!num_cu) {
             int dev = 0;
