@@ -43,6 +43,7 @@
 #include <stdlib.h>
 #include "common.h"
 #include "gemm_ws.h"
+#include "gemm_ws64.h"
 using namespace mumpy;
 
 namespace {
@@ -755,6 +756,22 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
         } else if (ws_mode == 2) {
             if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.86 && K >= 128 && !(K >= 1024 && rounds >= 1.8)) how = 1;
             else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
+        }
+        // Mid-size shapes without a GELU epilogue: the same design at 64x64 tiles, two workgroups per CU (gemm_ws64.h).  Fitted
+        // to same-device runs of tools/gemm_shapes.py with MUMPY_GEMM_WS64 = 0 / 1 / 2 (profiles/r02_gemm_ws64_shapes.txt): it
+        // wins up to 32 chunks deep when the tiles fill at most one round of the 2 x CUs slots or at least 2.5, and for the
+        // short-K shapes (<= 12 chunks) in between; deeper K wants the tiled kernels' split-K, a GELU epilogue is bound by the
+        // epilogue waves (two matrix waves per SIMD leave them even fewer issue slots).  =0 disables it, =2 forces it.
+        static const int ws64_mode = getenv("MUMPY_GEMM_WS64") ? atoi(getenv("MUMPY_GEMM_WS64")) : 1;
+        if (!how && !conv && ws64_mode) {
+            const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
+            const double r64 = (double)t64 / (2.0 * num_cu);
+            const bool fits = ws64_mode == 2 || (act != MUMPY_ACT_GELU && nk <= 32 && t64 >= 64 && (r64 <= 1.0 || r64 >= 2.5 || nk <= 12));
+            if (fits) {
+                if (int rc = gemm_ws64::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s)) return rc;
+                MUMPY_CHECK_LAUNCH("linear(ws64)");
+                return 0;
+            }
         }
         if (how) {
             if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0, nullptr, ws_clean,

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <vector>
 #include "../../multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd/csrc/gemm_ws.h"
+#include "../../multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd/csrc/gemm_ws64.h"
 
 namespace mumpy {
 void set_error(const char* fmt, ...) { fprintf(stderr, "error: %s\n", fmt); }
@@ -97,6 +98,7 @@ int main(int argc, char** argv) {
     dev_cu = prop.multiProcessorCount;
     const int grid_override = getenv("WS_GRID") ? atoi(getenv("WS_GRID")) : 0;
     const int force_split = getenv("WS_SPLIT") ? atoi(getenv("WS_SPLIT")) : -1;
+    const bool tile64 = getenv("WS_TILE") && atoi(getenv("WS_TILE")) == 64;      // the 64x64-tile kernel of gemm_ws64.h
     const int reps = getenv("WS_REPS") ? atoi(getenv("WS_REPS")) : 20;
     printf("%s, %d CUs, LDS %d B per workgroup, dbg %d\n", prop.name, dev_cu, mumpy::gemm_ws::LDS_BYTES, mumpy::gemm_ws::DBG);
     hipStream_t s;
@@ -136,7 +138,11 @@ int main(int argc, char** argv) {
         CK(hipMemsetAsync(Y, 0xff, ny * 4, s));
         if (is_conv ? !mumpy::gemm_ws::conv_eligible(sh.M, sh.N, cvd) : !mumpy::gemm_ws::eligible(sh.M, sh.N, sh.K)) { printf("%-10s %d %d %d not eligible\n", sh.tag, sh.M, sh.N, sh.K); continue; }
         const int cu = grid_override ? grid_override : dev_cu;
-        if (mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps, false, cv)) return 1;
+        auto go = [&]() {
+            return tile64 ? mumpy::gemm_ws64::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s)
+                          : mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps, false, cv);
+        };
+        if (go()) return 1;
         CK(hipGetLastError());
         if (is_conv)
             ref_conv_kernel<<<dim3((sh.N + 255) / 256, sh.M), 256, 0, s>>>(X, W, B, sh.res ? R : nullptr, Yr, sh.B, sh.H, sh.W, sh.C, sh.N, sh.kh, sh.kw, sh.act);
@@ -155,9 +161,9 @@ int main(int argc, char** argv) {
         }
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        for (int i = 0; i < 3; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps, false, cv);
+        for (int i = 0; i < 3; ++i) go();
         CK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps; ++i) mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps, false, cv);
+        for (int i = 0; i < reps; ++i) go();
         CK(hipEventRecord(e1, s));
         CK(hipStreamSynchronize(s));
         float ms = 0;
