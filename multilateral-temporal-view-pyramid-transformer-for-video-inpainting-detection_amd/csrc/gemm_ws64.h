@@ -235,8 +235,10 @@ __global__ __launch_bounds__(768, 6) void gemm_ws64_kernel(Params p) {
 
 inline bool eligible(int64_t M, int N, int K) { return gemm_ws::eligible(M, N, K); }
 
+// per_cu: workgroups per CU (2, or 1: the launch then claims the CU's LDS so that a second workgroup cannot join -- with a
+// GELU epilogue one matrix wave per SIMD leaves the epilogue waves enough issue slots, two do not)
 inline int launch(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N, int K,
-                  int act, int num_cu, hipStream_t s) {
+                  int act, int num_cu, hipStream_t s, int per_cu = 2) {
     Params p;
     p.cv_H = p.cv_W = p.cv_C = p.cv_kh = p.cv_kw = p.cv_cpc = 0;
     p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
@@ -251,7 +253,8 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     const int need = (PASSES + p.nk - 2) / (p.nk - 1);           // passes per chunk so that a tile's epilogue fits under the next tile
     const int P = need <= 1 ? 1 : need <= 2 ? 2 : 4;
     p.lmin = 0;
-    const unsigned slots = 2u * (unsigned)num_cu;
+    const unsigned slots = (unsigned)per_cu * (unsigned)num_cu;
+    const int lds_bytes = per_cu == 1 ? 2 * LDS_BYTES + 1024 : LDS_BYTES;
     const unsigned grid = p.tiles < slots ? p.tiles : slots;
     p.st_w = (p.gn % 4 == 0) ? 4u : (p.gn % 2 == 0) ? 2u : 1u;
     p.rr_G = grid;
@@ -262,11 +265,11 @@ inline int launch(const float* x, const float* W, const float* bias, const float
         static bool attr_set = false;                                                                                   \
         if (!attr_set) {                                                                                                \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws64_kernel<P_>),                     \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
-            if (e != hipSuccess) { set_error("gemm_ws64: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LDS_BYTES + 1024);       \
+            if (e != hipSuccess) { set_error("gemm_ws64: cannot reserve %d B of LDS: %s", 2 * LDS_BYTES + 1024, hipGetErrorString(e)); return (int)e; } \
             attr_set = true;                                                                                            \
         }                                                                                                               \
-        hipLaunchKernelGGL(gemm_ws64_kernel<P_>, dim3(grid), dim3(768), LDS_BYTES, s, p);                               \
+        hipLaunchKernelGGL(gemm_ws64_kernel<P_>, dim3(grid), dim3(768), lds_bytes, s, p);                               \
     } while (0)
     if (P == 1) MUMPY_WS64_LAUNCH(1);
     else if (P == 2) MUMPY_WS64_LAUNCH(2);

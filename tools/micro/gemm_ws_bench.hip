@@ -139,7 +139,7 @@ int main(int argc, char** argv) {
         if (is_conv ? !mumpy::gemm_ws::conv_eligible(sh.M, sh.N, cvd) : !mumpy::gemm_ws::eligible(sh.M, sh.N, sh.K)) { printf("%-10s %d %d %d not eligible\n", sh.tag, sh.M, sh.N, sh.K); continue; }
         const int cu = grid_override ? grid_override : dev_cu;
         auto go = [&]() {
-            return tile64 ? mumpy::gemm_ws64::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s)
+            return tile64 ? mumpy::gemm_ws64::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, getenv("WS64_ONE") ? 1 : 2)
                           : mumpy::gemm_ws::launch(X, W, B, sh.res ? R : nullptr, Y, sh.M, sh.N, sh.K, sh.act, cu, s, wsp, wsb, force_split, stamps, false, cv);
         };
         if (go()) return 1;
