@@ -20,7 +20,7 @@ F, W = agg("FETCH_SIZE"), agg("WRITE_SIZE")
 short = lambda k: re.sub(r"\(anonymous namespace\)::|^void ", "", k).split("(")[0]
 forwards = next(n for k, (n, _) in F.items() if "final_conv_kernel" in k)
 rows = sorted(((2 * f + W.get(k, [0, 0])[1], short(k), n, 2 * f, W.get(k, [0, 0])[1]) for k, (n, f) in F.items()), reverse=True)
-is_gemm = lambda n: (n.startswith("linear_kernel") and ", true," not in n.split("<")[1][:24]) or "gemm_ws_kernel" in n
+is_gemm = lambda n: (n.startswith("linear_kernel") and ", true," not in n.split("<")[1][:24]) or "gemm_ws_kernel" in n or "gemm_ws64_kernel" in n
 gemm = [r for r in rows if is_gemm(r[1]) or r[1].startswith("splitk_reduce")]
 # ABI launches of mumpy_linear_wsz_fwd + mumpy_linear_rows_fwd per forward = non-conv linear_kernel + gemm_ws_kernel dispatches
 abi_launches = sum(r[2] for r in gemm if is_gemm(r[1]))
