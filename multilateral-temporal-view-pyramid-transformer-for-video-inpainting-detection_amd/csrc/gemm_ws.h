@@ -47,7 +47,6 @@ constexpr int E_DW = BM * BN;
 constexpr int E_OFF_DW = NSTAGE * STAGE_DW;
 constexpr int LDS_BYTES = (E_OFF_DW + E_DW) * 4;
 constexpr int PASSES = BM / 8;              // epilogue passes per tile: 8 rows (4 helper waves x 2 rows) each
-constexpr unsigned NG = 4;                  // N-tiles per group of the tile order
 #ifndef MUMPY_WS_DBG
 #define MUMPY_WS_DBG 0      // harness diagnostics, compile time (a runtime switch would put branches around the loads): 1 = no operand loads, 2 = no epilogue, 4 = no LDS staging writes, 8 = no priority
 #endif
@@ -113,11 +112,10 @@ __device__ __forceinline__ void tile_coords(const Params& p, unsigned v, unsigne
     }
 }
 
-// First chunk of workgroup b (b = G: one past the end).  Whole-tile mode: tile boundaries.  Split mode: an even share of
-// the chunk sequence, moved to the tile boundary when it would leave a head part shorter than lmin chunks (the epilogue of
-// the tile before it needs that many chunks to run under) or a tail part of one or two chunks (not worth a slab).
-__device__ __host__ __forceinline__ unsigned first_chunk(unsigned b, unsigned G, unsigned tiles, unsigned units, int nk, int lmin, bool split) {
-    if (!split) return (unsigned)(((uint64_t)b * tiles) / G) * (unsigned)nk;
+// Split schedule: first chunk of workgroup b (b = G: one past the end) -- an even share of the chunk sequence, moved to the
+// tile boundary when it would leave a head part shorter than lmin chunks (the epilogue of the tile before it needs that many
+// chunks to run under) or a tail part of one or two chunks (not worth a slab).
+__device__ __host__ __forceinline__ unsigned first_chunk(unsigned b, unsigned G, unsigned units, int nk, int lmin) {
     unsigned u = (unsigned)(((uint64_t)b * units) / G);
     const unsigned r = u % (unsigned)nk;
     if (r != 0 && r < (unsigned)lmin) u -= r;
@@ -571,9 +569,9 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
         const unsigned tile_end = (prev_t + 1) * nk;
         if (hl == 0) {
             for (unsigned b2 = b + 1; b2 < G; ++b2) {
-                const unsigned f0 = first_chunk(b2, G, p.tiles, p.units, p.nk, p.lmin, true);
+                const unsigned f0 = first_chunk(b2, G, p.units, p.nk, p.lmin);
                 if (f0 >= tile_end) break;
-                if (first_chunk(b2 + 1, G, p.tiles, p.units, p.nk, p.lmin, true) == f0) continue;        // empty workgroup
+                if (first_chunk(b2 + 1, G, p.units, p.nk, p.lmin) == f0) continue;        // empty workgroup
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.flags + b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24))
                     __builtin_amdgcn_s_sleep(8);
@@ -586,9 +584,9 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
         // sum the parts in chunk order into the image (fixed order: bitwise reproducible)
         float* const Ew = lds + E_OFF_DW;
         for (unsigned b2 = b + 1; b2 < G; ++b2) {
-            const unsigned f0 = first_chunk(b2, G, p.tiles, p.units, p.nk, p.lmin, true);
+            const unsigned f0 = first_chunk(b2, G, p.units, p.nk, p.lmin);
             if (f0 >= tile_end) break;
-            if (first_chunk(b2 + 1, G, p.tiles, p.units, p.nk, p.lmin, true) == f0) continue;
+            if (first_chunk(b2 + 1, G, p.units, p.nk, p.lmin) == f0) continue;
             const float* sl = p.slabs + (size_t)b2 * E_DW + e_row * BN + 4 * e_c4;
 #pragma unroll 4
             for (int e = 0; e < PASSES; ++e) {
@@ -618,8 +616,8 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     const bool split = p.flags != nullptr;
     unsigned u0, u1;
     if (split) {
-        u0 = first_chunk(b, G, p.tiles, p.units, p.nk, p.lmin, true);
-        u1 = first_chunk(b + 1, G, p.tiles, p.units, p.nk, p.lmin, true);
+        u0 = first_chunk(b, G, p.units, p.nk, p.lmin);
+        u1 = first_chunk(b + 1, G, p.units, p.nk, p.lmin);
     } else {                                        // whole tiles, dealt round-robin: virtual ids b rr_cnt .. + own count
         const unsigned cnt = b < p.tiles ? (p.tiles - b + G - 1) / G : 0;
         u0 = b * p.rr_cnt * (unsigned)p.nk;
