@@ -60,6 +60,22 @@ def test_linear(m, n, k, act, res):
     assert rel_err(y.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("m,n,k", [(1568, 1152, 384), (392, 2304, 768), (25088, 288, 96), (1000, 320, 96), (1960, 768, 768), (6250, 192, 192)])
+def test_linear_mid_size_shapes_on_the_64x64_persistent_kernel(m, n, k):
+    """Shapes the planner gives to csrc/gemm_ws64.h (no GELU, <= 32 chunks deep, tiles filling one round of the 2 x CU slots
+    or many): bias + residual epilogue, ragged last row tile, y aliasing the residual, bitwise repeatability."""
+    x, w, b = seeded_randn(m + 1, m, k).to(DEV), (seeded_randn(n + 2, n, k) / k ** 0.5).to(DEV), seeded_randn(k + 3, n).to(DEV)
+    r = seeded_randn(m + n, m, n).to(DEV)
+    y = ops.linear(x, w, b, residual=r)
+    ref = F.linear(x.cpu().double(), w.cpu().double(), b.cpu().double()) + r.cpu().double()
+    assert rel_err(y.cpu(), ref) < 1e-5
+    assert torch.equal(y, ops.linear(x, w, b, residual=r))
+    out = r.clone()
+    ops.linear(x, w, b, residual=out, out=out)
+    assert torch.equal(out, y)
+    assert rel_err(ops.linear(x, w, None).cpu(), F.linear(x.cpu().double(), w.cpu().double())) < 1e-5
+
+
 def test_linear_no_bias_and_alias():
     x, w = seeded_randn(1, 200, 128).to(DEV), seeded_randn(2, 128, 128).to(DEV) / 11
     r = seeded_randn(3, 200, 128).to(DEV)
