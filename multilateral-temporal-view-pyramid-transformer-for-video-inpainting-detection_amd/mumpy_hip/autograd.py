@@ -28,12 +28,16 @@ def _grad_slot(p):
 
 
 class LinearFn(torch.autograd.Function):
+    """y = x W^T + b [+ residual]: with a residual the add rides in the GEMM epilogue (as in the inference forward) and its
+    gradient is dy itself."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, residual=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
         ctx.slots = (_grad_slot(weight), _grad_slot(bias) if bias is not None else None)
-        return ops.linear(x, weight, bias)
+        return ops.linear(x, weight, bias, residual=residual)
 
     @staticmethod
     def backward(ctx, dy):
@@ -46,7 +50,7 @@ class LinearFn(torch.autograd.Function):
             dx = ops.linear(dy2, ops.transpose(weight)).reshape(x.shape) if need_dx else None
             dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)) if need_dw else None
             db = ops.col_sum(dy2) if need_db else None
-            return dx, dw, db
+            return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
         m = dy2.shape[0]
         wslot, bslot = ctx.slots
         # large token counts: dX on the forward GEMM (the wave-specialised kernel) against a transposed copy of W -- the
@@ -56,11 +60,19 @@ class LinearFn(torch.autograd.Function):
                                     dw_out=wslot if need_dw else None, db_out=bslot if need_db else None)
         if big:
             dx = ops.linear(dy2, ops.transpose(weight))
-        return (dx.reshape(x.shape) if need_dx else None), dw, db
+        return (dx.reshape(x.shape) if need_dx else None), dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
 LEGACY_LINEAR_BWD = os.environ.get("MUMPY_LEGACY_LINEAR_BWD", "0") != "0"   # the first version's route (transposes + forward GEMM), for A/B runs
 BIG_DGRAD_ROWS = 4096
+
+
+def _residual_linear(x_res, drop_path, inp, lin_w, lin_b):
+    """x_res + drop_path(Linear(inp)): one launch when stochastic depth is inactive (eval mode / rate 0), else the taped
+    Linear, the per-sample scale and the add."""
+    if not drop_path.training or getattr(drop_path, "drop_prob", 0.0) <= 0.0:
+        return LinearFn.apply(inp, lin_w, lin_b, x_res)
+    return AddFn.apply(x_res, drop_path_train(drop_path, LinearFn.apply(inp, lin_w, lin_b)))
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -188,10 +200,10 @@ def swin_block_train(block, x):
     qkv = LinearFn.apply(y, att.qkv.weight, att.qkv.bias)
     a = WindowAttentionFn.apply(qkv, att.relative_position_bias_table, att.relative_position_index,
                                 (b, hs, w, block.dim, block.shift_size, att.scale), tab, ids)
-    x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
+    x = _residual_linear(x, block.drop_path, a, att.proj.weight, att.proj.bias)
     x, z = ResidualLayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, block.mlp.fc1.weight, block.mlp.fc1.bias))
-    return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, block.mlp.fc2.weight, block.mlp.fc2.bias)))
+    return _residual_linear(x, block.drop_path, hmid, block.mlp.fc2.weight, block.mlp.fc2.bias)
 
 
 def patch_merging_train(pm, x):
@@ -369,11 +381,11 @@ def global_block_train(block, x):
     att = block.attn.unwrapped
     x, y = ResidualLayerNormFn.apply(x, block.norm1.weight, block.norm1.bias, block.norm1.eps)
     a = TemporalAttentionFn.apply(LinearFn.apply(y, att.qkv.weight, att.qkv.bias), att.heads, att.scale)
-    x = AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(a, att.proj.weight, att.proj.bias)))
+    x = _residual_linear(x, block.drop_path, a, att.proj.weight, att.proj.bias)
     x, z = ResidualLayerNormFn.apply(x, block.norm2.weight, block.norm2.bias, block.norm2.eps)
     mlp = block.mlp.unwrapped
     hmid = GeluFn.apply(LinearFn.apply(z, mlp.fc1.weight, mlp.fc1.bias))
-    return AddFn.apply(x, drop_path_train(block.drop_path, LinearFn.apply(hmid, mlp.fc2.weight, mlp.fc2.bias)))
+    return _residual_linear(x, block.drop_path, hmid, mlp.fc2.weight, mlp.fc2.bias)
 
 
 # ---------------------------------------------------------------------------------------------- pyramid Decoder (row 15)
@@ -578,7 +590,7 @@ def cross_swin_block_train(blk, x1, x2):
         x1 = AddFn.apply(x1, drop_path_train(blk.drop_path, yw.reshape(b, l1, c1)))       # window-major y added to raster x1 (mTVE:285-286)
     x1, z = ResidualLayerNormFn.apply(x1, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps)
     hmid = GeluFn.apply(LinearFn.apply(z, blk.mlp.fc1.weight, blk.mlp.fc1.bias))
-    return AddFn.apply(x1, drop_path_train(blk.drop_path, LinearFn.apply(hmid, blk.mlp.fc2.weight, blk.mlp.fc2.bias))), out
+    return _residual_linear(x1, blk.drop_path, hmid, blk.mlp.fc2.weight, blk.mlp.fc2.bias), out
 
 
 def encoder_train(enc, x):
