@@ -310,18 +310,14 @@ def add(a, b, out=None):
     return out
 
 
-_REL_INDEX32 = {}
-
-
 def rel_index32(index: torch.Tensor) -> torch.Tensor:
-    """The (49*49,) int32 image of a `relative_position_index` buffer on its device, cached per buffer (the buffer is a
-    constant of the model: the conversion used to be two launches per W-MSA call of a training step)."""
-    key = (index.data_ptr(), str(index.device), index._version)
-    t = _REL_INDEX32.get(key)
-    if t is None:
-        if len(_REL_INDEX32) > 512:
-            _REL_INDEX32.clear()
-        t = _REL_INDEX32[key] = index.to(torch.int32).reshape(-1).contiguous()
+    """The (49*49,) int32 image of a `relative_position_index` buffer on its device, kept ON the buffer object (the buffer is a
+    constant of the model; the conversion used to be two launches per W-MSA call of a training step).  A module moved with
+    `.to(device)` gets new buffer objects, hence a fresh image."""
+    t = getattr(index, "_mumpy_i32", None)
+    if t is None or t.device != index.device or getattr(index, "_mumpy_i32_version", -1) != index._version:
+        t = index.to(torch.int32).reshape(-1).contiguous()
+        index._mumpy_i32, index._mumpy_i32_version = t, index._version
     return t
 
 
