@@ -207,26 +207,100 @@ def cpu_baseline(frames, sample_b):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` invoked plainly (no torch.distributed.run): start N fresh child processes, one rank per
-    GPU, and relay rank 0's JSON line.  Children, never a re-exec: this parent has not touched the GPU and never will
-    (replaces the reference's in-process nn.DataParallel fan-out, test.py:56-58)."""
+    GPU, supervise ALL of them and relay rank 0's JSON line.  Children, never a re-exec: this parent has not touched the
+    GPU and never will (replaces the reference's in-process nn.DataParallel fan-out, test.py:56-58).
+    Fail fast: the first rank that exits non-zero ends the job -- the others are terminated (SIGTERM, then SIGKILL), the
+    parent exits non-zero with that rank's stderr tail and prints no JSON line; ranks that ran into a taken rendezvous
+    port (picked by bind-then-close, so another process can grab it in between) are relaunched on a fresh port."""
     import socket
     import subprocess
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
-    sys.stdout.flush()
-    if any(rcs):
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    import tempfile
+    deadline = time.monotonic() + float(os.environ.get("MUMPY_BENCH_JOB_TIMEOUT", "3000"))
+
+    def launch(port, tmp):
+        procs, logs = [], []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            out = open(os.path.join(tmp, f"rank{r}.out"), "wb")       # files, not pipes: no rank can block on a full pipe
+            err = open(os.path.join(tmp, f"rank{r}.err"), "wb")
+            logs.append((out, err))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=out, stderr=err))
+        return procs, logs
+
+    def tail(tmp, r, n=2000):
+        try:
+            with open(os.path.join(tmp, f"rank{r}.err"), "rb") as f:
+                return f.read()[-n:].decode(errors="replace")
+        except OSError:
+            return ""
+
+    def stop(procs):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    for attempt in range(3):
+        with socket.socket() as sk:
+            sk.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        with tempfile.TemporaryDirectory(prefix="mumpy_bench_") as tmp:
+            procs, logs = launch(port, tmp)
+            failed = None
+            shown = 0
+            try:
+                while True:
+                    rcs = [p.poll() for p in procs]
+                    # relay rank 0's progress lines (stderr) as they come
+                    try:
+                        with open(os.path.join(tmp, "rank0.err"), "rb") as f:
+                            f.seek(shown)
+                            chunk = f.read()
+                        if chunk:
+                            shown += len(chunk)
+                            sys.stderr.write(chunk.decode(errors="replace"))
+                            sys.stderr.flush()
+                    except OSError:
+                        pass
+                    bad = [r for r, rc in enumerate(rcs) if rc not in (None, 0)]
+                    if bad:
+                        failed = bad[0]
+                        break
+                    if all(rc == 0 for rc in rcs):
+                        break
+                    if time.monotonic() > deadline:
+                        failed = -1
+                        break
+                    time.sleep(0.05)
+            finally:
+                stop(procs)
+                for out, err in logs:
+                    out.close()
+                    err.close()
+            if failed is None:
+                with open(os.path.join(tmp, "rank0.out"), "rb") as f:
+                    sys.stdout.write(f.read().decode())
+                sys.stdout.flush()
+                return
+            if failed == -1:
+                raise SystemExit("bench.py: job timeout (MUMPY_BENCH_JOB_TIMEOUT) -- ranks terminated, no result")
+            rc, msg = procs[failed].returncode, tail(tmp, failed)
+            port_taken = any(("EADDRINUSE" in tail(tmp, r, 8000) or "address already in use" in tail(tmp, r, 8000).lower())
+                             for r in range(args.gpus))
+        if port_taken and attempt < 2:
+            print(f"[bench] rendezvous port {port} was taken; relaunching the ranks on a fresh port", file=sys.stderr, flush=True)
+            continue
+        sys.stderr.write(f"[bench] rank {failed} exited with code {rc}; the other ranks were terminated.  Its stderr tail:\n{msg}\n")
+        raise SystemExit(rc if isinstance(rc, int) and 0 < rc < 256 else 1)
 
 
 def rehearse(args, world, rank):
@@ -234,6 +308,10 @@ def rehearse(args, world, rank):
     max-over-ranks timing and JSON line as the real run.  Needs no GPU (gloo)."""
     from mumpy_hip import distributed as D
     backend = os.environ.get("MUMPY_BENCH_BACKEND", "gloo")
+    die = os.environ.get("MUMPY_REHEARSE_DIE", "")           # "<rank>:<code>": that rank exits before the rendezvous
+    if die and int(die.split(":")[0]) == rank:
+        print(f"rehearsal: rank {rank} exiting with code {die.split(':')[1]} before rendezvous", file=sys.stderr, flush=True)
+        raise SystemExit(int(die.split(":")[1]))
     D.init_process_group(backend, None)
     if world > 1:
         dist.barrier()

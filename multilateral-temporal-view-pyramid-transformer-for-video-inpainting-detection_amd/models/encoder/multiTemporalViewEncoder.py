@@ -14,7 +14,7 @@ import torch.nn as nn
 from models.modules.blocks import Block
 from models.modules.dct import FAF
 from models.modules.deformableAttention import SwinDAttention
-from models.modules.layers import Derived, DropPath, to_2tuple, trunc_normal_
+from models.modules.layers import Derived, DropPath, refuse_stochastic_depth, to_2tuple, trunc_normal_
 from models.modules.swinTransformer import Mlp, SwinTransformerBlock, ThreeViewPatchMerging, WindowAttention
 from mumpy_hip import ops
 from mumpy_hip.streams import run_parallel
@@ -64,7 +64,8 @@ class CrossSwinBlock(nn.Module):
         what the next view's cross attention consumes: mTVE:275, 347-349)."""
         h, w = self.input_resolution
         b, l1, c1 = x1.shape
-        self.drop_path(x1)
+        if self.training:
+            refuse_stochastic_depth(self)
         if ops.storage() == "bf16":                              # config 3: bf16 LN output / qkv / attention output
             from models.modules.swinTransformer import _w16
             a = self.attn.attend(ops.layernorm_bf16(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, l1 // w, w, 0, None)

@@ -6,7 +6,7 @@ launch for all sites and heads -> proj GEMM(+residual) -> LN -> fc1 GEMM(+GELU) 
 """
 import torch.nn as nn
 
-from models.modules.layers import DropPath
+from models.modules.layers import DropPath, refuse_stochastic_depth
 from mumpy_hip import ops
 
 
@@ -70,7 +70,8 @@ class Block(nn.Module):
     def forward(self, x, mask=None, return_attention=False):
         if return_attention:
             raise NotImplementedError("attention maps are not materialised")
-        self.drop_path(x)
+        if self.training:
+            refuse_stochastic_depth(self)
         x, _ = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), mask, residual=x)
         if ops.storage() == "bf16" and isinstance(self.mlp, FeedForward):
             return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)

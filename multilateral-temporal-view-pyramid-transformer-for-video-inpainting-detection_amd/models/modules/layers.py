@@ -36,6 +36,14 @@ class DropPath(nn.Module):
         return f"drop_prob={self.drop_prob}"
 
 
+def refuse_stochastic_depth(module):
+    """The inference forwards fold the residual add into the GEMM epilogue and never call `drop_path`; in train mode with a
+    non-zero rate that would silently skip stochastic depth, so they refuse instead (training goes through mumpy_hip.autograd)."""
+    if module.training and getattr(module.drop_path, "drop_prob", 0.0) > 0.0:
+        raise NotImplementedError("the inference forward has no stochastic depth: call .eval(), or train through "
+                                  "mumpy_hip.autograd (swin_block_train / encoder_train / baseline_encoder_train)")
+
+
 class ConfigDict(dict):
     """Nested dict with attribute access: the part of ml_collections.ConfigDict the factory and the encoder use
     (item access `cfg["patches"].size`, attribute access `cfg.window_size`)."""

@@ -10,7 +10,7 @@ LN, QKV GEMM, window attention, proj GEMM(+residual), LN, fc1 GEMM(+GELU), fc2 G
 import torch
 import torch.nn as nn
 
-from models.modules.layers import Derived, DropPath, to_2tuple, trunc_normal_
+from models.modules.layers import Derived, DropPath, refuse_stochastic_depth, to_2tuple, trunc_normal_
 from mumpy_hip import ops
 
 
@@ -157,7 +157,8 @@ class SwinTransformerBlock(nn.Module):
         b, l, c = x.shape
         assert l % (h * w) == 0, "input feature has wrong size"
         hs = l // w                                              # frames stacked on rows (swin:267)
-        self.drop_path(x)                                        # raises in training mode with stochastic depth
+        if self.training:
+            refuse_stochastic_depth(self)
         if ops.storage() == "bf16":                              # config 3: bf16 tensors between the kernels of the block
             a = self.attn.attend(ops.layernorm_bf16(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs, w,
                                  self.shift_size, self.attn_mask)

@@ -16,13 +16,20 @@ from . import ops
 
 
 def _grad_slot(p):
-    """The buffer a parameter's gradient is accumulated into by the backward kernels themselves: its `.grad` when that is a
-    dense fp32 tensor of the parameter's shape (FlatAdamW points `.grad` at views of its flat gradient buffer) -- autograd
-    then receives None for it and launches no add."""
+    """The buffer a parameter's gradient is accumulated into by the backward kernels themselves, or None.  Opt-in: only a
+    parameter that FlatAdamW has adopted (it points `.grad` at a view of its flat gradient buffer and records that view as
+    `p._mumpy_flat_grad`) and whose `.grad` is STILL that view qualifies -- autograd then receives None for it and launches no
+    add.  Resolved at BACKWARD time (the Functions keep the parameter objects, not the slots): a `.grad` that was re-pointed
+    or set to None between forward and backward, parameters with hooks, and `torch.autograd.grad(inputs=[param])` all take
+    the ordinary route in which the kernel returns dW / db to autograd."""
     if p is None or not p.is_leaf:
         return None
     g = p.grad
-    if g is not None and g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape and not g.requires_grad:
+    if g is None or g is not getattr(p, "_mumpy_flat_grad", None):
+        return None
+    if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+        return None
+    if g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape and not g.requires_grad:
         return g
     return None
 
@@ -36,7 +43,7 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
-        ctx.slots = (_grad_slot(weight), _grad_slot(bias) if bias is not None else None)
+        ctx.params = (weight, bias)
         return ops.linear(x, weight, bias, residual=residual)
 
     @staticmethod
@@ -52,12 +59,14 @@ class LinearFn(torch.autograd.Function):
             db = ops.col_sum(dy2) if need_db else None
             return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
         m = dy2.shape[0]
-        wslot, bslot = ctx.slots
+        wslot, bslot = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
         # large token counts: dX on the forward GEMM (the wave-specialised kernel) against a transposed copy of W -- the
         # copy is weight-sized and the product runs at 100+ TFLOP/s; everything else in one call, no copies
         big = need_dx and m >= BIG_DGRAD_ROWS
-        dx, dw, db = ops.linear_bwd(x2.contiguous(), weight, dy2, need_dx=need_dx and not big, need_dw=need_dw, need_db=need_db,
-                                    dw_out=wslot if need_dw else None, db_out=bslot if need_db else None)
+        dx = dw = db = None
+        if (need_dx and not big) or need_dw or need_db:          # (a frozen Linear with a big input needs only the GEMM below)
+            dx, dw, db = ops.linear_bwd(x2.contiguous(), weight, dy2, need_dx=need_dx and not big, need_dw=need_dw, need_db=need_db,
+                                        dw_out=wslot if need_dw else None, db_out=bslot if need_db else None)
         if big:
             dx = ops.linear(dy2, ops.transpose(weight))
         return (dx.reshape(x.shape) if need_dx else None), dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
@@ -80,7 +89,7 @@ class LayerNormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps):
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
-        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        ctx.params = (gamma, beta)
         return ops.layernorm(x, gamma, beta, eps)
 
     @staticmethod
@@ -91,7 +100,7 @@ class LayerNormFn(torch.autograd.Function):
 
 
 def _ln_backward(ctx, x, gamma, dy, dx_add):
-    gslot, bslot = ctx.slots
+    gslot, bslot = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
     both = gslot is not None and bslot is not None and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]
     return ops.layernorm_bwd(x, gamma, dy.contiguous(), ctx.eps, dx_add=None if dx_add is None else dx_add.contiguous(),
                              dg_out=gslot if both else None, db_out=bslot if both else None)
@@ -105,7 +114,7 @@ class ResidualLayerNormFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, eps):
         ctx.save_for_backward(x, gamma)
         ctx.eps = eps
-        ctx.slots = (_grad_slot(gamma), _grad_slot(beta))
+        ctx.params = (gamma, beta)
         return x.view_as(x), ops.layernorm(x, gamma, beta, eps)
 
     @staticmethod
@@ -176,7 +185,7 @@ class WindowAttentionFn(torch.autograd.Function):
         bias_pad = ops.expand_relpos_bias(table.detach(), idx32)
         ctx.save_for_backward(qkv, bias_pad, idx32)
         ctx.dims, ctx.mask = dims, (mask_tab, mask_id)
-        ctx.slot = _grad_slot(table)
+        ctx.table = table
         return ops.window_attention(qkv, bias_pad, b, hs, w, c, shift, scale, mask_tab, mask_id)
 
     @staticmethod
@@ -184,7 +193,7 @@ class WindowAttentionFn(torch.autograd.Function):
         qkv, bias_pad, idx32 = ctx.saved_tensors
         b, hs, w, c, shift, scale = ctx.dims
         dqkv, dtable = ops.window_attention_bwd(qkv, dout.contiguous(), bias_pad, idx32, b, hs, w, c, shift, scale, *ctx.mask,
-                                                dtable_out=ctx.slot if ctx.needs_input_grad[1] else None)
+                                                dtable_out=_grad_slot(ctx.table) if ctx.needs_input_grad[1] else None)
         return dqkv, dtable, None, None, None, None
 
 

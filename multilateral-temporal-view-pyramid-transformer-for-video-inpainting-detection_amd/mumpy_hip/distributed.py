@@ -12,13 +12,18 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group(backend: str = "nccl", device: torch.device = None):
-    """Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run sets them)."""
+def init_process_group(backend: str = "nccl", device: torch.device = None, timeout_s: float = None):
+    """Reads RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT from the environment (torch.distributed.run sets them).
+    The rendezvous / collective timeout is explicit (MUMPY_DIST_TIMEOUT seconds, default 300): a rank that never arrives
+    makes the others raise within minutes instead of sitting in the store for c10d's 10-30 minute default."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
-        dist.init_process_group(backend, **kw)
+        if timeout_s is None:
+            timeout_s = float(os.environ.get("MUMPY_DIST_TIMEOUT", "300"))
+        dist.init_process_group(backend, timeout=datetime.timedelta(seconds=timeout_s), **kw)
     return int(os.environ.get("RANK", "0")), world
 
 

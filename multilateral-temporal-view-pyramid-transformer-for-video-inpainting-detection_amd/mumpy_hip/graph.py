@@ -30,7 +30,8 @@ class GraphedForward:
         # launches use -- captured on another stream, every GEMM would record a zero-fill of a fresh 17 MB workspace
         # (0.86 ms per forward of fill kernels in the first round-2 profile)
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.static_x.device)
+            from .streams import new_distinct_stream       # never a handle that a fork/join side stream already wraps
+            self._side = new_distinct_stream(self.static_x.device, (torch.cuda.current_stream().cuda_stream,))
         side = self._side
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side), torch.no_grad():          # warm the derived-table caches off the graph

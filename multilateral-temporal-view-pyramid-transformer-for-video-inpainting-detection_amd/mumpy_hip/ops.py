@@ -172,21 +172,35 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
 
 
 _KEPT_WS = {}
+_RETIRED_WS = []          # superseded workspaces: never freed (a captured hipGraph may have their address baked in)
 
 
 def _kept_workspace(nbytes, device):
     """One zero-initialised workspace per (device, stream), grown on demand and kept: launches on one stream execute in
     order, so they can share it; the persistent GEMM's arrival flags (its first page) return to zero after every launch
     (mumpy_linear_wsz_fwd), so nothing has to be reset between launches.  Allocated outside any graph capture (the eager
-    warm-up pass that precedes a capture creates the buffers the captured launches then point at)."""
+    warm-up pass that precedes a capture creates the buffers the captured launches then point at).
+    Lifetime: a workspace that is outgrown is RETIRED, not freed -- GraphedForward / GraphedTrainStep replays keep writing
+    flags and slabs through the address they captured, so handing that memory back to the caching allocator would let a
+    later tensor alias it.  (Two torch Stream objects with one raw handle are one HIP stream: sharing a workspace between
+    them is the in-order case above; mumpy_hip.streams never hands out a side stream whose handle aliases its parent.)"""
     s = torch.cuda.current_stream(device)
     key = (str(device), s.cuda_stream)
     ws = _KEPT_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         if torch.cuda.is_current_stream_capturing():
             return torch.zeros(nbytes // 4, device=device, dtype=torch.float32)     # (captured fill: still correct, just not free)
+        if ws is not None:
+            _RETIRED_WS.append(ws)
         ws = _KEPT_WS[key] = torch.zeros(max(nbytes // 4, 1024), device=device, dtype=torch.float32)
     return ws
+
+
+def reset_workspaces():
+    """Re-zero every kept workspace (arrival-flag pages included).  For use after a launch reported an error or was
+    aborted mid-kernel: the persistent GEMM's flags are only guaranteed to be back at zero after a launch that completed."""
+    for ws in list(_KEPT_WS.values()) + _RETIRED_WS:
+        ws.zero_()
 
 
 def linear_rows(x_view, weight, bias=None, residual=None, out=None):

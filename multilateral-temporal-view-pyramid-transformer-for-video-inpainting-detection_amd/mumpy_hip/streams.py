@@ -15,12 +15,25 @@ _DEPTH = [0]            # nesting depth of run_parallel on this (host) thread: n
 SERIAL = os.environ.get("MUMPY_SERIAL", "0") == "1"
 
 
+def new_distinct_stream(device, avoid=(), priority=0):
+    """A torch stream whose raw HIP handle differs from every handle in `avoid` and from every side stream of this module.
+    torch hands pool streams out round-robin (32 per priority): after enough requests a "new" Stream object wraps a handle
+    that is already in use, which would make a fork run on its own parent (silently serial) or two graphs share a side
+    stream.  Streams drawn and rejected here are dropped again (they are pool members, nothing is destroyed)."""
+    taken = {int(h) for h in avoid} | {s.cuda_stream for s in _SIDE.values()}
+    for _ in range(64):
+        s = torch.cuda.Stream(device=device, priority=priority)
+        if s.cuda_stream not in taken:
+            return s
+    raise RuntimeError("mumpy_hip.streams: torch's stream pool is exhausted (more than 32 concurrent side streams)")
+
+
 def _side_stream(device, i, parent=None):
     # keyed by the PARENT stream as well: two forks at the same depth under different parents never share a side stream
     key = (str(device), _DEPTH[0], i, None if parent is None else parent.cuda_stream)
     if key not in _SIDE:
         prio = int(os.environ.get("MUMPY_SIDE_PRIORITY", "0"))      # (high priority measured slightly slower)
-        _SIDE[key] = torch.cuda.Stream(device=device, priority=prio)
+        _SIDE[key] = new_distinct_stream(device, () if parent is None else (parent.cuda_stream,), prio)
     return _SIDE[key]
 
 

@@ -68,6 +68,7 @@ class FlatAdamW:
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p._mumpy_flat_grad = p.grad           # marker: the backward kernels may accumulate into this view (autograd._grad_slot)
         self.base_lr = self.lr = lr
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.steps = 0            # optimizer steps taken
@@ -196,7 +197,8 @@ class GraphedTrainStep:
                 o.step_dev()
                 o.zero_grad()
 
-        side = torch.cuda.Stream()
+        from .streams import new_distinct_stream
+        side = new_distinct_stream(self.x.device, (torch.cuda.current_stream().cuda_stream,))
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):                      # warm-up steps are real steps (caches, allocator, lazy inits)

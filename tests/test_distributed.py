@@ -92,6 +92,26 @@ def test_bench_plain_multi_gpu_invocation_spawns_ranks():
     assert out["eval_metric"]["clips"] == 16          # both ranks' micro-batches went through the one all-reduce
 
 
+def test_bench_spawned_rank_failure_ends_the_job_fast():
+    """Rank 1 exits with code 3 before the rendezvous: the parent must notice (it supervises every child, not only rank 0),
+    terminate rank 0 -- which is sitting in the store waiting for its peer --, exit non-zero with rank 1's code and stderr
+    tail, and print no JSON line; well inside 30 s, not after the process-group timeout."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(MUMPY_BENCH_BACKEND="gloo", MUMPY_REHEARSE_DIE="1:3")
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse"],
+                       env=env, capture_output=True, text=True, timeout=120)
+    dt = time.monotonic() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr[-2000:])
+    assert dt < 30, f"took {dt:.1f} s"
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")], r.stdout
+    assert "rank 1 exited with code 3" in r.stderr and "before rendezvous" in r.stderr
+
+
 def test_bench_rejects_mismatched_world_before_touching_a_gpu():
     import subprocess
     import sys

@@ -160,3 +160,25 @@ def test_clip_frame_indices_clamp():
     assert c5 == [[0, 0, 0, 1, 2], [0, 0, 1, 2, 2], [0, 1, 2, 2, 2]]
     assert all(len(c) == 5 for c in clip_frame_indices(10, 4))              # even length_clip -> 2k+1 = 5 frames
     assert clip_frame_indices(0, 3) == []
+
+
+def test_inference_forward_refuses_stochastic_depth_in_train_mode():
+    """The inference forwards fold the residual add into the GEMM epilogue and never apply DropPath: in train mode with a
+    non-zero rate they refuse explicitly (before any kernel launch); eval mode and rate 0 pass the guard (and then fail on
+    the CPU tensor, since there is no CPU path)."""
+    from models.modules.blocks import Block
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = SwinTransformerBlock(96, (7, 7), 3, window_size=7, shift_size=0, drop_path=0.1)
+    x = torch.zeros(1, 49, 96)
+    blk.train()
+    with pytest.raises(NotImplementedError, match="stochastic depth"):
+        blk(x)
+    blk.eval()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        blk(x)
+    g = Block(128, 2, 256, 0.0, 0.2).train()
+    with pytest.raises(NotImplementedError, match="stochastic depth"):
+        g(torch.zeros(2, 3, 128))
+    g0 = Block(128, 2, 256, 0.0, 0.0).train()                 # rate 0: nothing to skip, the guard lets it through
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        g0(torch.zeros(2, 3, 128))

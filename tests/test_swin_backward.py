@@ -100,10 +100,64 @@ def test_hip_linear_fn_accumulates_into_grad_slots():
         wd, bd = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
         if slots:
             wd.grad, bd.grad = torch.full_like(wd, 0.5), torch.full_like(bd, -0.25)
+            wd._mumpy_flat_grad, bd._mumpy_flat_grad = wd.grad, bd.grad        # the opt-in marker FlatAdamW sets
+            slot_w = wd.grad
         AG.LinearFn.apply(xd, wd, bd).backward(g.cuda())
         off_w, off_b = (0.5, -0.25) if slots else (0.0, 0.0)
         assert rel_err(xd.grad.cpu(), xr.grad) < 2e-5
         assert rel_err(wd.grad.cpu() - off_w, wr.grad) < 2e-5 and rel_err(bd.grad.cpu() - off_b, br.grad) < 2e-5
+        if slots:
+            assert wd.grad is slot_w                                           # accumulated in place by the kernel
+
+
+@pytest.mark.gpu
+def test_hip_linear_fn_grad_slot_is_opt_in_and_resolved_at_backward():
+    """The in-kernel gradient accumulation needs FlatAdamW's marker and is resolved in backward: (i) a plain pre-existing .grad
+    is accumulated by autograd, and parameter hooks see the gradient; (ii) a .grad re-pointed between forward and backward
+    (zero_grad(set_to_none=True) of another optimizer) receives the gradient instead of an orphaned buffer;
+    (iii) torch.autograd.grad(inputs=[param]) returns it."""
+    from mumpy_hip import autograd as AG
+    x, w, g = seeded_randn(1, 64, 96), seeded_randn(2, 32, 96) / 96 ** 0.5, seeded_randn(4, 64, 32)
+    wr = w.clone().requires_grad_(True)
+    F.linear(x, wr).backward(g)
+    # (i) unmarked .grad + hook
+    wd = torch.nn.Parameter(w.cuda())
+    wd.grad = torch.full_like(wd, 0.5)
+    seen = []
+    wd.register_hook(lambda t: seen.append(t.clone()))
+    AG.LinearFn.apply(x.cuda(), wd, None).backward(g.cuda())
+    assert len(seen) == 1 and rel_err(seen[0].cpu(), wr.grad) < 2e-5
+    assert rel_err(wd.grad.cpu() - 0.5, wr.grad) < 2e-5
+    # (ii) marker present at forward, .grad dropped before backward
+    wd = torch.nn.Parameter(w.cuda())
+    wd.grad = torch.zeros_like(wd)
+    wd._mumpy_flat_grad = orphan = wd.grad
+    y = AG.LinearFn.apply(x.cuda(), wd, None)
+    wd.grad = None
+    y.backward(g.cuda())
+    assert not orphan.any() and rel_err(wd.grad.cpu(), wr.grad) < 2e-5
+    # (iii) autograd.grad on a marked parameter
+    wd = torch.nn.Parameter(w.cuda())
+    wd.grad = torch.zeros_like(wd)
+    wd._mumpy_flat_grad = wd.grad
+    y = AG.LinearFn.apply(x.cuda(), wd, None)
+    (gw,) = torch.autograd.grad(y, [wd], g.cuda())
+    assert rel_err(gw.cpu(), wr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_linear_fn_frozen_weight_with_many_rows():
+    """A frozen Linear (weight.requires_grad=False) whose input needs a gradient, at M >= BIG_DGRAD_ROWS: only the dX GEMM runs
+    (mumpy_linear_bwd would reject a call with nothing to compute)."""
+    from mumpy_hip import autograd as AG
+    m = AG.BIG_DGRAD_ROWS + 64
+    x, w, g = seeded_randn(1, m, 96), seeded_randn(2, 64, 96) / 96 ** 0.5, seeded_randn(4, m, 64)
+    xr = x.clone().requires_grad_(True)
+    F.linear(xr, w).backward(g)
+    xd = x.cuda().requires_grad_(True)
+    wd = torch.nn.Parameter(w.cuda(), requires_grad=False)
+    AG.LinearFn.apply(xd, wd, None).backward(g.cuda())
+    assert rel_err(xd.grad.cpu(), xr.grad) < 2e-5
 
 
 @pytest.mark.gpu
