@@ -293,7 +293,10 @@ int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, int64_t works
  * (deep contractions are split over workgroups into workspace slabs and reduced in split order).
  * db costs no launch of its own when dW is computed too (row sums of the dY tiles the dW product stages anyway).
  * workspace: mumpy_linear_bwd_workspace_bytes(M,N,K) bytes of device scratch (required for db without dW; without it the
- * products are not split). */
+ * products are not split).
+ * accumulate | MUMPY_MATH_BF16: the same products with both operands rounded to bf16 (RNE) while staged and multiplied on
+ * v_mfma_f32_32x32x16_bf16, fp32 accumulation, fp32 tensors in memory (config 5's arithmetic; db sums the rounded dY as a
+ * bf16 autocast backward does).  Still one call, no transposed copies. */
 int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M, int N, int K,
                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
@@ -302,8 +305,8 @@ int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx,
  * dW (Cout,kh,kw,Cin) (+)= sum over output pixels p of dy[p][:] (x) x[p + tap displacement][:], taps outside the image
  * contributing zero -- ONE launch over all taps on the NHWC tensors as they are (no padded or shifted copies, no transposes):
  * x (B,H,W,Cin), dy (B,H,W,Cout) NHWC; stride 1, odd taps, zero "same" padding; Cin % 32 == 0, Cout % 32 == 0.
- * accumulate = 1: dW += (the caller's flat gradient buffer).  Deterministic (pixel ranges split over workgroups into workspace
- * slabs, reduced in split order).  workspace: mumpy_conv2d_wgrad_workspace_bytes(...) bytes (optional: without it no split). */
+ * accumulate = 1: dW += (the caller's flat gradient buffer); | MUMPY_MATH_BF16: bf16 operands as in mumpy_linear_bwd.
+ * Deterministic (pixel ranges split over workgroups into workspace slabs, reduced in split order).  workspace: mumpy_conv2d_wgrad_workspace_bytes(...) bytes (optional: without it no split). */
 int64_t mumpy_conv2d_wgrad_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw);
 int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* dW, int B, int H, int W, int Cin, int Cout, int kh, int kw,
                             int accumulate, void* workspace, int64_t workspace_bytes, void* stream);

@@ -19,9 +19,10 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
                                                              const float* __restrict__ ln_b,
                                                              const float* __restrict__ pw_w, float* __restrict__ pos,
                                                              int H, int W, int C, int nWx, int nWf) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * WT * Cg];   // static: up to 100 KB at Cg = 256
+    __shared__ __attribute__((aligned(16))) float sm[2 * WT * Cg + 25 * Cg];   // static: up to 126 KB at Cg = 256
     float* tile = sm;             // [49][Cg]
     float* conv = sm + WT * Cg;   // [49][Cg]
+    float* wsm = sm + 2 * WT * Cg;   // [Cg][25] depthwise taps
     const int bw = blockIdx.x, g = blockIdx.y;
     const int b = bw / nWf, n = bw - b * nWf;
     const int wy = n / nWx, wx = n - wy * nWx;
@@ -34,13 +35,17 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
         const int tok = window_token(wy, wx, p, H, W, 0);
         *reinterpret_cast<f32x4*>(tile + p * Cg + 4 * c4) = *reinterpret_cast<const f32x4*>(qb + (int64_t)tok * C + 4 * c4);
     }
+    // the group's 25 taps per channel: coalesced into LDS first.  (Each thread used to gather its 25 taps from global memory
+    // at a 100-byte lane stride: ~50 cache lines per load instruction, 25 of them per thread -- the texture-address path
+    // of a CU serialised the six resident blocks for 24-44 us per launch, most of the kernel's time.)
+    for (int idx = tid; idx < 25 * Cg; idx += 256) wsm[idx] = dw_w[idx];
     // 256 % Cg == 0 (Cg in {32,64,128,256}): a thread keeps one channel for all its pixels
     const int cc = tid % Cg;
-    float wreg[25];
-#pragma unroll
-    for (int i = 0; i < 25; ++i) wreg[i] = dw_w[cc * 25 + i];
     const float breg = dw_b[cc];
     __syncthreads();
+    float wreg[25];
+#pragma unroll
+    for (int i = 0; i < 25; ++i) wreg[i] = wsm[cc * 25 + i];          // 25 is odd: lanes hit distinct banks
     for (int p = tid / Cg; p < WT; p += 256 / Cg) {
         const int py = p / WS, px = p - py * WS;
         // branch-free taps: out-of-window taps read the centre pixel and contribute fmaf(0, w, acc) == acc, so the 25 LDS

@@ -205,6 +205,181 @@ __global__ __launch_bounds__(256) void xgemm_kernel(XArgs a) {
         }
 }
 
+// ---- bf16 OPERAND mode (MUMPY_MATH_BF16 OR-ed into `accumulate`; config 5's arithmetic, train.py:94-138 under bf16) --------
+// Same products, same tensors in memory (fp32), same split / reduce / accumulate contract; the operands are rounded to bf16
+// (RNE, v_cvt_pk_bf16_f32) while they are staged and multiplied on v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  A lane
+// of that MFMA supplies EIGHT consecutive contraction values of one row, so both LDS images are [row][k] (32 bf16 = 16 dwords
+// per row, padded to 20: conflict-free ds_read_b128 fragments).  An operand whose contraction index is the slow one in memory
+// ([k][col]: dY and x of the dW product, W of the dX product) is transposed IN REGISTERS on its way to LDS: a thread loads the
+// PIECES (k) x 4 (col) block k = kb PIECES .. +PIECES-1, cols 4 cq .. +3 as PIECES 16-byte loads (lanes: kb fastest, so the
+// 64-128 contiguous bytes of a k row are read by neighbouring lanes and the PIECES bf16 of a column land in consecutive LDS
+// dwords of neighbouring lanes -- at most the 2-way conflict that 64 lanes x 8 B have anyway) and writes one 4/8-byte
+// k-run per column.  No transposed copies in HBM, no extra launches: the first version of the bf16 mode ran three transpose
+// kernels + two forward GEMMs + a column sum per Linear and ~45 launches per convolution weight gradient.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+template <int WT, bool A_T, bool CONV = false>
+__global__ __launch_bounds__(256) void xgemm16_kernel(XArgs a) {
+    constexpr int BT = 2 * WT, NB = WT / 32;
+    constexpr int LDH = 20;                      // dwords per LDS row: 32 bf16 + 4 dwords of padding
+    constexpr int PIECES = BT / 32;              // 16-B pieces per thread and operand per chunk (4 or 2)
+    constexpr int KB = BK / PIECES;              // k blocks of a chunk (8 or 16)
+    constexpr int CQW = 64 / KB;                 // column quads per wave (8 or 4)
+    __shared__ __attribute__((aligned(16))) uint32_t As[BT * LDH];
+    __shared__ __attribute__((aligned(16))) uint32_t Bs[BT * LDH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+    const int tile = blockIdx.x, z = blockIdx.y;
+    const int tr = tile / a.gc, tc = tile - tr * a.gc;
+    const int row0 = tr * BT, col0 = tc * BT;
+    const int ch0 = z * a.chunks_per_split;
+    int ch1 = ch0 + a.chunks_per_split;
+    if (ch1 > a.nchunks) ch1 = a.nchunks;
+    const int tap = CONV ? (int)blockIdx.z : 0;
+    const int tap_r = CONV ? tap / a.cv_kw : 0, tap_s = CONV ? tap - tap_r * a.cv_kw : 0;
+    const int dr = tap_r - a.cv_ph, dc = tap_s - a.cv_pw;
+    const int64_t tap_shift = CONV ? (int64_t)dr * a.cvW + dc : 0;
+    // transposing loader: this thread's k block and column quad
+    const int kb = lane & (KB - 1), cq = (lane / KB) + CQW * wave;
+
+    f32x4 pa0[PIECES], pb0[PIECES], pa1[PIECES], pb1[PIECES];
+    auto fetch = [&](int ch, f32x4 (&pa)[PIECES], f32x4 (&pb)[PIECES]) {
+        const int k0 = ch * BK;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int k = k0 + kb * PIECES + i;
+            if (A_T) {
+                const int r = row0 + 4 * cq;
+                pa[i] = (k < a.KK && r < a.R) ? *reinterpret_cast<const f32x4*>(a.A + (int64_t)k * a.lda + r) : f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {
+                const int p = tid + 256 * i;
+                int r = row0 + (p >> 3);
+                if (r > a.R - 1) r = a.R - 1;            // rows past the edge: clamped, their products are never stored
+                pa[i] = *reinterpret_cast<const f32x4*>(a.A + (int64_t)r * a.lda + k0 + 4 * (p & 7));
+            }
+            const int cc = col0 + 4 * cq;
+            bool ok = k < a.KK && cc < a.C;
+            if (CONV) {
+                const unsigned img = __umulhi((unsigned)k, a.cv_mhw) >> a.cv_shw, rem = (unsigned)k - img * (unsigned)(a.cvH * a.cvW);
+                const unsigned yy = __umulhi(rem, a.cv_mw) >> a.cv_sw, xx = rem - yy * (unsigned)a.cvW;
+                ok = ok && (unsigned)((int)yy + dr) < (unsigned)a.cvH && (unsigned)((int)xx + dc) < (unsigned)a.cvW;
+            }
+            pb[i] = ok ? *reinterpret_cast<const f32x4*>(a.B + ((int64_t)k + tap_shift) * a.ldb + cc) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // k-run of column j of a transposed block: PIECES bf16 at [4 cq + j][kb PIECES ..]
+    auto put_t = [&](uint32_t* img, const f32x4 (&pv)[PIECES]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            uint32_t* dst = img + (4 * cq + j) * LDH + (kb * PIECES) / 2;
+            if (PIECES == 4) {
+                const bf16x2 lo = __builtin_convertvector(f32x2{pv[0][j], pv[1][j]}, bf16x2);
+                const bf16x2 hi = __builtin_convertvector(f32x2{pv[PIECES - 2][j], pv[PIECES - 1][j]}, bf16x2);
+                uint2 w;
+                w.x = __builtin_bit_cast(uint32_t, lo); w.y = __builtin_bit_cast(uint32_t, hi);
+                *reinterpret_cast<uint2*>(dst) = w;
+            } else {
+                const bf16x2 lo = __builtin_convertvector(f32x2{pv[0][j], pv[PIECES - 1][j]}, bf16x2);
+                *dst = __builtin_bit_cast(uint32_t, lo);
+            }
+        }
+    };
+    auto stage = [&](const f32x4 (&pa)[PIECES], const f32x4 (&pb)[PIECES]) {
+        if (A_T) put_t(As, pa);
+        else {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int p = tid + 256 * i;
+                const bf16x2 lo = __builtin_convertvector(f32x2{pa[i].x, pa[i].y}, bf16x2), hi = __builtin_convertvector(f32x2{pa[i].z, pa[i].w}, bf16x2);
+                uint2 w;
+                w.x = __builtin_bit_cast(uint32_t, lo); w.y = __builtin_bit_cast(uint32_t, hi);
+                *reinterpret_cast<uint2*>(&As[(p >> 3) * LDH + 2 * (p & 7)]) = w;
+            }
+        }
+        put_t(Bs, pb);
+    };
+
+    f32x16 acc[NB][NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // MFMA step st of a chunk: lane (c, h) supplies k = 16 st + 8 h .. + 7 of row c
+    const uint32_t* const a_f = As + (wm * WT + c) * LDH + 4 * h;
+    const uint32_t* const b_f = Bs + (wn * WT + c) * LDH + 4 * h;
+    const bool want_rowsum = A_T && a.rowsum != nullptr && tc == 0 && tap == 0;
+    float rowsum = 0.f;
+    auto compute = [&]() {
+        if (A_T && want_rowsum && tid < BT) {        // bias gradient from the bf16-rounded dY tile (as a bf16 autocast backward sums it)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(&As[tid * LDH + 4 * q]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) rowsum += (float)v[e];
+            }
+        }
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {
+            bf16x8 fa[NB], fb[NB];
+#pragma unroll
+            for (int i = 0; i < NB; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(a_f + 32 * i * LDH + 8 * st);
+#pragma unroll
+            for (int j = 0; j < NB; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(b_f + 32 * j * LDH + 8 * st);
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (ch0 < ch1) fetch(ch0, pa0, pb0);
+    if (ch0 + 1 < ch1) fetch(ch0 + 1, pa1, pb1);
+    for (int ch = ch0; ch < ch1; ch += 2) {
+        __syncthreads();
+        stage(pa0, pb0);
+        __syncthreads();
+        if (ch + 2 < ch1) fetch(ch + 2, pa0, pb0);
+        compute();
+        if (ch + 1 < ch1) {
+            __syncthreads();
+            stage(pa1, pb1);
+            __syncthreads();
+            if (ch + 3 < ch1) fetch(ch + 3, pa1, pb1);
+            compute();
+        }
+    }
+
+    if (A_T && want_rowsum && tid < BT && row0 + tid < a.R) {
+        if (a.ks > 1) a.rowsum_slabs[(int64_t)z * a.R + row0 + tid] = rowsum;
+        else a.rowsum[row0 + tid] = a.rowsum_accum ? a.rowsum[row0 + tid] + rowsum : rowsum;
+    }
+    // accumulator (i, j)[r]: wave row 32 i + (r&3) + 8 (r>>2) + 4 h, wave column 32 j + c (both images are [row][k]: no permutation)
+    float* dst;
+    int64_t ldd;
+    if (a.ks > 1) { dst = a.slabs + ((int64_t)z * gridDim.z + tap) * a.R * a.C; ldd = a.C; }
+    else { dst = a.out + (int64_t)tap * a.C; ldd = a.ldo; }
+    const bool accum = a.ks == 1 && a.accum;
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wm * WT + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = col0 + wn * WT + 32 * j + c;
+                if (row < a.R && col < a.C) {
+                    float* o = dst + (int64_t)row * ldd + col;
+                    float v = acc[i][j][r];
+                    if (accum) v += *o;
+                    *o = v;
+                }
+            }
+}
+
 // out = (accum ? out : 0) + slab[0] + slab[1] + ... in split order (fixed: bitwise reproducible); n4 = R C / 4, dense
 struct RowSumArgs { const float* slabs; float* out; int R, accum; };     // the bias-gradient partials ride in the same launch
 
@@ -326,7 +501,7 @@ int64_t colsum_blocks(int64_t R) {
 // rowsum (A_T only): also write / accumulate the row sums of A over the contraction (the bias gradient) -- the slab layout
 // is [ks][R][C] followed by [ks][R] row-sum partials
 int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int R, int C, int KK,
-                 int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0) {
+                 int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0, bool bf16 = false) {
     XPlan p = plan(R, C, KK);
     if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * (C + (rowsum ? 1 : 0)) * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
     XArgs a;
@@ -335,7 +510,15 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
     a.R = R; a.C = C; a.KK = KK; a.ks = p.ks; a.chunks_per_split = p.cps; a.nchunks = p.nchunks; a.accum = accum; a.gc = p.gc;
     a.cvH = a.cvW = a.cv_kw = a.cv_ph = a.cv_pw = 0; a.cv_mhw = a.cv_shw = a.cv_mw = a.cv_sw = 0;
     const dim3 grid((unsigned)(p.gr * p.gc), (unsigned)p.ks);
-    if (p.wt == 64) {
+    if (bf16) {
+        if (p.wt == 64) {
+            if (a_t) hipLaunchKernelGGL((xgemm16_kernel<64, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((xgemm16_kernel<64, false>), grid, dim3(256), 0, s, a);
+        } else {
+            if (a_t) hipLaunchKernelGGL((xgemm16_kernel<32, true>), grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((xgemm16_kernel<32, false>), grid, dim3(256), 0, s, a);
+        }
+    } else if (p.wt == 64) {
         if (a_t) hipLaunchKernelGGL((xgemm_kernel<64, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((xgemm_kernel<64, false>), grid, dim3(256), 0, s, a);
     } else {
@@ -377,7 +560,8 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
                   "linear_bwd: need N %% 32 == 0 and K %% 32 == 0 (got M=%lld N=%d K=%d)", (long long)M, N, K);
     MUMPY_REQUIRE(aligned16(x) && aligned16(W) && aligned16(dy) && aligned16(dx) && aligned16(dW) && aligned16(db) && aligned16(workspace),
                   MUMPY_EALIGN, "linear_bwd: pointers must be 16-byte aligned");
-    MUMPY_REQUIRE((accumulate & ~3) == 0, MUMPY_EINVAL, "linear_bwd: unknown accumulate bits 0x%x", accumulate);
+    MUMPY_REQUIRE((accumulate & ~(3 | MUMPY_MATH_BF16)) == 0, MUMPY_EINVAL, "linear_bwd: unknown accumulate bits 0x%x", accumulate);
+    const bool bf16 = (accumulate & MUMPY_MATH_BF16) != 0;
     MUMPY_REQUIRE(!workspace || workspace_bytes >= mumpy_linear_bwd_workspace_bytes(M, N, K), MUMPY_EINVAL,
                   "linear_bwd: workspace too small");
     MUMPY_REQUIRE(!db || dW || workspace, MUMPY_ENULL, "linear_bwd: db without dW needs the workspace");
@@ -398,10 +582,10 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
         MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
     }
     if (dx)          // dX[M,K] = dY[M,N] W[N,K]
-        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s)) return rc;
+        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s, nullptr, 0, bf16)) return rc;
     if (dW)          // dW[N,K] (+)= dY^T X
         if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s, db,
-                                  (accumulate >> 1) & 1)) return rc;
+                                  (accumulate >> 1) & 1, bf16)) return rc;
     return 0;
 }
 
@@ -427,7 +611,9 @@ extern "C" int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* d
     MUMPY_REQUIRE(B > 0 && H > 0 && W >= 2 && (int64_t)B * H * W < (1ll << 31) - 256, MUMPY_EINVAL, "conv2d_wgrad: bad image batch %dx%dx%d", B, H, W);
     MUMPY_REQUIRE(kh > 0 && kw > 0 && (kh & 1) && (kw & 1), MUMPY_EINVAL, "conv2d_wgrad: kernel %dx%d must be odd (same padding)", kh, kw);
     MUMPY_REQUIRE(Cin % 32 == 0 && Cout % 32 == 0, MUMPY_EINVAL, "conv2d_wgrad: Cin=%d and Cout=%d must be multiples of 32", Cin, Cout);
-    MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "conv2d_wgrad: accumulate must be 0 or 1");
+    MUMPY_REQUIRE((accumulate & ~(1 | MUMPY_MATH_BF16)) == 0, MUMPY_EINVAL, "conv2d_wgrad: accumulate is 0 / 1, optionally | MUMPY_MATH_BF16");
+    const bool bf16 = (accumulate & MUMPY_MATH_BF16) != 0;
+    accumulate &= 1;
     const int P = B * H * W, taps = kh * kw;
     XPlan p = plan(Cout, Cin, P, taps);
     if (p.ks > 1 && (!workspace || (int64_t)p.ks * taps * Cout * Cin * 4 > workspace_bytes)) { p.ks = 1; p.cps = p.nchunks; }
@@ -441,7 +627,9 @@ extern "C" int mumpy_conv2d_wgrad_nhwc(const float* x, const float* dy, float* d
     magic_div31((unsigned)W, a.cv_mw, a.cv_sw);
     hipStream_t s = as_stream(stream);
     const dim3 grid((unsigned)(p.gr * p.gc), (unsigned)p.ks, (unsigned)taps);
-    if (p.wt == 64) hipLaunchKernelGGL((xgemm_kernel<64, true, true>), grid, dim3(256), 0, s, a);
+    if (bf16 && p.wt == 64) hipLaunchKernelGGL((xgemm16_kernel<64, true, true>), grid, dim3(256), 0, s, a);
+    else if (bf16) hipLaunchKernelGGL((xgemm16_kernel<32, true, true>), grid, dim3(256), 0, s, a);
+    else if (p.wt == 64) hipLaunchKernelGGL((xgemm_kernel<64, true, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((xgemm_kernel<32, true, true>), grid, dim3(256), 0, s, a);
     MUMPY_CHECK_LAUNCH("conv2d_wgrad(product)");
     if (p.ks > 1) {

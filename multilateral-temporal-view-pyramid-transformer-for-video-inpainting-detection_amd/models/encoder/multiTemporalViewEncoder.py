@@ -75,7 +75,16 @@ class CrossSwinBlock(nn.Module):
         out = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
         return ops.add(x1, out), out
 
-    def tail(self, x1, x2):
+    def prep(self, x1):
+        """The part of the cross attention that needs only this view's tokens (q projection + sampling positions): off the
+        dependency chain msa(next view) -> pre -> sampling -> ... when it is issued before the wait for the next view."""
+        if self.last_view:
+            return None
+        h, w = self.input_resolution
+        b, l1, _ = x1.shape
+        return self.cva.crossattn._prep(x1, (b, l1 // w, w))
+
+    def tail(self, x1, x2, prep=None):
         """Second half: deformable cross-view attention against x2 (skipped for the last view) and the MLP."""
         h, w = self.input_resolution
         b, l1, c1 = x1.shape
@@ -83,7 +92,7 @@ class CrossSwinBlock(nn.Module):
         if not self.last_view:
             hs2 = x2.shape[1] // w
             x2p = ops.linear(x2, self.pre.weight, self.pre.bias)                    # per-token, raster (mTVE:283)
-            yt = self.cva.crossattn.attend_raster(x1, x2p, b, hs1, w, hs2)
+            yt = self.cva.crossattn.attend_raster(x1, x2p, b, hs1, w, hs2, prep)
             # x1 + [x1 in window order] + [scrambled proj_out]  (mTVE:138, 285-286; deform:403)
             x1 = ops.deform_combine(x1, yt, b, hs1, w, c1)
         if ops.storage() == "bf16":
@@ -117,8 +126,9 @@ class CrossThreeViewSwinBlock(nn.Module):
         independent and a view's cross attention needs only the NEXT view's W-MSA output, so the block runs as three
         branches with two cross-branch events:
             current stream:  msa3 --(out3)--> mlp3
-            side A:          msa2 --(out2)--> [wait out3] cva2 + mlp2
-            side B:          msa1 ----------> [wait out2] cva1 + mlp1                                             """
+            side A:          msa2 --(out2)--> q2/offsets2 [wait out3] cva2 + mlp2
+            side B:          msa1 ----------> q1/offsets1 [wait out2] cva1 + mlp1
+        (the q projection and the offset network of a view need only its own tokens: they are issued before the wait)"""
         from mumpy_hip import streams
         if streams.SERIAL:
             x3, out3 = self.block3(x[2], x[2])
@@ -138,16 +148,18 @@ class CrossThreeViewSwinBlock(nn.Module):
             with torch.cuda.stream(sa):
                 x2a, out2 = self.block2.msa(x[1])
                 e2.record(sa)
+                prep2 = self.block2.prep(x2a)
                 sa.wait_event(e3)
                 out3.record_stream(sa)
-                x2 = self.block2.tail(x2a, out3)
+                x2 = self.block2.tail(x2a, out3, prep2)
             sb.wait_event(fork)
             x[0].record_stream(sb)
             with torch.cuda.stream(sb):
                 x1a, _ = self.block1.msa(x[0])
+                prep1 = self.block1.prep(x1a)
                 sb.wait_event(e2)
                 out2.record_stream(sb)
-                x1 = self.block1.tail(x1a, out2)
+                x1 = self.block1.tail(x1a, out2, prep1)
             x3 = self.block3.tail(x3a, None)
         finally:
             streams._DEPTH[0] -= 1

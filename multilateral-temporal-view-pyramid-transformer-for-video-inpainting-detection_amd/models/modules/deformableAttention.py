@@ -62,7 +62,17 @@ class SwinDAttention(nn.Module):
         nn.init.zeros_(self.proj_out.bias)
         self._wkv, self._bkv, self._pad = Derived(), Derived(), Derived()
 
-    def _run(self, x1, x2, q_grid, kv_grid):
+    def _prep(self, x1, q_grid):
+        """The q side, which needs nothing from the other view: q = proj_q(x1) and the sampling positions of the offset
+        network (deform:332-349).  The cross block runs this BEFORE it waits for the other view's tokens."""
+        b, h, w = q_grid
+        q = ops.linear(x1, self.proj_q.weight, self.proj_q.bias)
+        off = self.conv_offset
+        pos = ops.deform_offsets(q, off[0].weight, off[0].bias, off[1].norm.weight, off[1].norm.bias, off[3].weight,
+                                 b, h, w, self.nc)
+        return q, pos
+
+    def _run(self, x1, x2, q_grid, kv_grid, prep=None):
         """q_grid = (b, h, w): x1 is (b, h*w, C) raster;  kv_grid = (b2, hs2, w2): x2 is (b2, hs2*w2, C) raster.
         Returns proj_out output Yt (nq, 49, C): window-major, token-major, i.e. BEFORE the deform:403 reshape."""
         c = self.nc
@@ -72,10 +82,7 @@ class SwinDAttention(nn.Module):
         nkv = b2 * (hs2 // 7) * (w2 // 7)
         if nkv % nq:
             raise RuntimeError(f"SwinDAttention: {nkv} kv windows is not a multiple of {nq} q windows")
-        q = ops.linear(x1, self.proj_q.weight, self.proj_q.bias)
-        off = self.conv_offset
-        pos = ops.deform_offsets(q, off[0].weight, off[0].bias, off[1].norm.weight, off[1].norm.bias, off[3].weight,
-                                 b, h, w, c)
+        q, pos = prep if prep is not None else self._prep(x1, q_grid)
         sampled = ops.deform_sample(x2, pos, b2, hs2, w2, c, nq)
         wkv = self._wkv.get((self.proj_k.weight, self.proj_v.weight),
                             lambda: torch.cat([self.proj_k.weight.reshape(c, c), self.proj_v.weight.reshape(c, c)], 0))
@@ -85,10 +92,10 @@ class SwinDAttention(nn.Module):
         o = ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)   # (nq,49,C)
         return ops.linear(o, self.proj_out.weight, self.proj_out.bias)
 
-    def attend_raster(self, x1, x2, b, h, w, hs2):
+    def attend_raster(self, x1, x2, b, h, w, hs2, prep=None):
         """Fused-block entry: x1 (B, h*w, C) q-side tokens, x2 (B, hs2*w, C) kv-side tokens (already through
-        `pre`), both raster with frames stacked on rows."""
-        return self._run(x1, x2, (b, h, w), (b, hs2, w))
+        `pre`), both raster with frames stacked on rows.  prep: the result of `_prep(x1, (b, h, w))` if already computed."""
+        return self._run(x1, x2, (b, h, w), (b, hs2, w), prep)
 
     def forward(self, x1, x2, return_attention=False):
         """Reference signature (deform:324): x1 (B1,49,C) q windows, x2 (B2,49,C) kv windows, B2 = r*B1.

@@ -4,7 +4,8 @@ Every Function's forward and backward is a C-ABI kernel call; torch contributes 
 bookkeeping only.  Linear backward is one call, mumpy_linear_bwd (csrc/gemm_bwd.hip), on the row-major tensors as they are:
     dX = dY W,  dW (+)= dY^T X,  db (+)= column sums of dY
 with dW / db accumulated straight into the parameter's `.grad` when that is a view of FlatAdamW's flat gradient buffer.
-(The bf16 operand modes keep the first version's route: the forward GEMM on transposed copies.)
+(`set_matrix_math("bf16")` runs the same call with bf16 operands on the bf16 MFMA; only the split-precision modes keep the
+first version's route: the forward GEMM on transposed copies.)
 `swin_block_train(block, x)` runs a `models.modules.swinTransformer.SwinTransformerBlock` through these Functions, with the
 same maths as its inference forward (swin:259-307); in train mode stochastic depth draws a per-sample mask per branch.
 """
@@ -20,9 +21,10 @@ def _grad_slot(p):
     parameter that FlatAdamW has adopted (it points `.grad` at a view of its flat gradient buffer and records that view as
     `p._mumpy_flat_grad`) and whose `.grad` is STILL that view qualifies -- autograd then receives None for it and launches no
     add.  Resolved at BACKWARD time (the Functions keep the parameter objects, not the slots): a `.grad` that was re-pointed
-    or set to None between forward and backward, parameters with hooks, and `torch.autograd.grad(inputs=[param])` all take
-    the ordinary route in which the kernel returns dW / db to autograd."""
-    if p is None or not p.is_leaf:
+    or set to None between forward and backward and parameters with hooks take the ordinary route in which the kernel returns
+    dW / db to autograd.  `torch.autograd.grad(inputs=[adopted_param])` cannot be told apart from `.backward()` inside a
+    Function: it fails loudly ("appears to not have been used in the graph") unless run under `grad_slots(False)`."""
+    if p is None or not p.is_leaf or not _SLOTS_ON[0]:
         return None
     g = p.grad
     if g is None or g is not getattr(p, "_mumpy_flat_grad", None):
@@ -32,6 +34,25 @@ def _grad_slot(p):
     if g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape and not g.requires_grad:
         return g
     return None
+
+
+_SLOTS_ON = [True]
+
+
+class grad_slots:
+    """Context manager: `with grad_slots(False):` makes every backward return its parameter gradients to autograd (no in-kernel
+    accumulation into FlatAdamW's buffer) -- for torch.autograd.grad(inputs=[param]) and gradient inspection."""
+
+    def __init__(self, on: bool):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev, _SLOTS_ON[0] = _SLOTS_ON[0], self.on
+        return self
+
+    def __exit__(self, *exc):
+        _SLOTS_ON[0] = self.prev
+        return False
 
 
 class LinearFn(torch.autograd.Function):
@@ -52,8 +73,8 @@ class LinearFn(torch.autograd.Function):
         n, k = weight.shape
         dy2, x2 = dy.reshape(-1, n).contiguous(), x.reshape(-1, k)
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
-        if ops.matrix_math() != "fp32" or LEGACY_LINEAR_BWD:
-            # bf16 operand modes: the forward GEMM on transposed copies (its operand modes apply to the backward products too)
+        if ops.matrix_math() not in ("fp32", "bf16") or LEGACY_LINEAR_BWD:
+            # split-precision modes: the forward GEMM on transposed copies (its operand modes apply to the backward products too)
             dx = ops.linear(dy2, ops.transpose(weight)).reshape(x.shape) if need_dx else None
             dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)) if need_dw else None
             db = ops.col_sum(dy2) if need_db else None
@@ -284,9 +305,9 @@ class Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv2d_nhwc(dy, w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
         if ctx.needs_input_grad[1]:
-            if ops.matrix_math() == "fp32" and not LEGACY_LINEAR_BWD:
-                dw = ops.conv2d_wgrad(x, dy, kh, kw)               # one launch over all taps, no shifted copies
-            else:                                                  # bf16 operand modes: one forward GEMM per tap on copies
+            if ops.matrix_math() in ("fp32", "bf16") and not LEGACY_LINEAR_BWD:
+                dw = ops.conv2d_wgrad(x, dy, kh, kw)               # one launch over all taps, no shifted copies (fp32 or bf16 operands)
+            else:                                                  # split-precision modes: one forward GEMM per tap on copies
                 dyt = ops.transpose(dy2.contiguous(), 32)          # (Cout, Ppad)
                 xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, kw // 2, kw // 2, kh // 2, kh // 2))   # (B,H+2,W+2,Cin)
                 taps = []

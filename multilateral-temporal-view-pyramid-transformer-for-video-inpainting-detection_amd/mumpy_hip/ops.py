@@ -636,6 +636,10 @@ def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_d
     if wsb is None:
         wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_bwd_workspace_bytes(m, n, k))
     ws = _ws(wsb, dev)
+    if _MATH == MATH_BF16:
+        acc |= MATH_BF16                                      # bf16 operands on the bf16 MFMA, fp32 accumulate (config 5's arithmetic)
+    elif _MATH != MATH_FP32:
+        raise RuntimeError("linear_bwd: the split-precision modes have no one-call backward (autograd routes them through linear)")
     _call("mumpy_linear_bwd", _p(x2d), _p(weight), _p(dy2d), _p(dx), _p(dw), _p(db), m, n, k, acc, _p(ws), wsb, _stream(),
           work=2.0 * m * n * k * (int(need_dx) + int(need_dw)))
     return dx, (None if dw_out is not None else dw), (None if db_out is not None else db)
@@ -658,7 +662,10 @@ def conv2d_wgrad(x, dy, kh, kw, dw_out=None):
     if wsb is None:
         wsb = _WS_BYTES[key] = int(_lib().mumpy_conv2d_wgrad_workspace_bytes(b, h, w, cin, cout, kh, kw))
     ws = _ws(wsb, x.device) if wsb else None
-    _call("mumpy_conv2d_wgrad_nhwc", _p(x), _p(dy), _p(dw), b, h, w, cin, cout, kh, kw, int(acc), _p(ws), wsb, _stream(),
+    if _MATH not in (MATH_FP32, MATH_BF16):
+        raise RuntimeError("conv2d_wgrad: the split-precision modes have no one-launch weight gradient")
+    _call("mumpy_conv2d_wgrad_nhwc", _p(x), _p(dy), _p(dw), b, h, w, cin, cout, kh, kw, int(acc) | (MATH_BF16 if _MATH == MATH_BF16 else 0),
+          _p(ws), wsb, _stream(),
           work=2.0 * b * h * w * cout * kh * kw * cin)
     return None if acc else dw
 

@@ -4,9 +4,17 @@ The 12 global temporal ViT blocks (M = B*49*T rows: under-filled GEMMs) depend o
 everything in the decoder except gcm1 and the decoder_2..5 trunk depends only on the per-stage features and the DCT
 map.  So after the pyramid stages the graph forks:   [ global blocks ]  ||  [ decoder branches ]   -> join -> trunk.
 Bitwise identical to Decoder()(*Encoder()(x)) (same kernels, no atomics)."""
+import os
+
 import torch
 
 from .streams import run_parallel
+
+# Round 3 measurement (tools/phase_timeline.py --graph, each phase replayed from its own hipGraph): the global blocks alone take
+# 3.74 ms, the decoder branches alone 1.52 ms, forked against each other 5.54 ms -- WORSE than back to back (5.27 ms).  The
+# persistent GEMM of the global blocks holds every CU's whole LDS, so nothing of the decoder can share a CU with it; the fork
+# only interleaves the two kernel sequences (and their L2 footprints).  Default since round 3: back to back.
+FORK_GLOBAL_DECODER = os.environ.get("MUMPY_FORK_GLOBAL_DECODER", "0") == "1"
 
 
 @torch.no_grad()
@@ -19,8 +27,12 @@ def fused_forward(encoder, decoder, x, with_mask=False, thr=0.5):
     # the global blocks (a plain chain) go to the side stream; the decoder branches, which fork again, stay on the
     # current stream so that every nested fork is rooted on it (forking from a side stream inside hipGraph capture
     # crashed the ROCm 7.2 runtime)
-    (tokens,), br = run_parallel([lambda: (base.forward_global(views),), lambda: decoder._branches(view_x, ffinfo)],
-                                 [views, flat + [ffinfo]])
+    if FORK_GLOBAL_DECODER:
+        (tokens,), br = run_parallel([lambda: (base.forward_global(views),), lambda: decoder._branches(view_x, ffinfo)],
+                                     [views, flat + [ffinfo]])
+    else:
+        tokens = base.forward_global(views)
+        br = decoder._branches(view_x, ffinfo)
     b, _, c = tokens.shape
     final_x = tokens.reshape(b, 7, 7, c).permute(0, 3, 1, 2)              # encoder.py:16-17
     feats = decoder._trunk(final_x, br)

@@ -42,6 +42,65 @@ for _ in range(3):
 torch.cuda.synchronize()
 run(); torch.cuda.synchronize()
 tot = marks[0][1].elapsed_time(marks[-1][1])
+print("== eager launches with fork/join (host launch overhead included: ~10 us per C-ABI call)")
 for (n0, e0), (n1, e1) in zip(marks[:-1], marks[1:]):
     print(f"{n1:32s} {e0.elapsed_time(e1):7.3f} ms")
 print(f"{'TOTAL':32s} {tot:7.3f} ms")
+
+
+def graphed(fn, reps=20):
+    """Duration of `fn` replayed from its own hipGraph (what the phase costs inside the benchmark's replayed forward)."""
+    from mumpy_hip.streams import new_distinct_stream
+    side = new_distinct_stream(dev, (torch.cuda.current_stream().cuda_stream,))
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        for _ in range(2):
+            fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g, stream=side):
+        keep = fn()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    del keep
+    return e0.elapsed_time(e1) / reps
+
+
+if "--graph" in sys.argv:
+    print("== each phase replayed from its own hipGraph (inputs from an eager pass)")
+    with torch.no_grad():
+        toks = base.tokenize(x)
+        ff = base.faf.forward_frame(x, 1)
+        xs = toks
+        outs, total = [], 0.0
+        rows = [("tokenize", graphed(lambda: base.tokenize(x))), ("faf", graphed(lambda: base.faf.forward_frame(x, 1)))]
+        for s, layer in enumerate(base.layers.layers):
+            xin = xs
+            rows.append((f"stage{s} cross", graphed(lambda: layer.blocks[0](list(xin)))))
+            xc = layer.blocks[0](list(xin))
+            chain = lambda: run_parallel([lambda: layer._view_chain(0, xc[0]), lambda: layer._view_chain(1, xc[1]),
+                                          lambda: layer._view_chain(2, xc[2])], [(xc[0],), (xc[1],), (xc[2],)])
+            rows.append((f"stage{s} chains", graphed(chain)))
+            for v in range(3):
+                rows.append((f"   view {v + 1} chain alone", graphed(lambda: layer._view_chain(v, xc[v]))))
+            res = chain()
+            xs = [r[0] for r in res]; outs.append([r[1].unsqueeze(1) for r in res])
+        flat = [t for st in outs for t in st]
+        gd = lambda: run_parallel([lambda: (base.forward_global(xs),), lambda: dec._branches(outs, ff)], [xs, flat + [ff]])
+        rows.append(("global || decoder branches", graphed(gd)))
+        rows.append(("   global blocks alone", graphed(lambda: base.forward_global(xs))))
+        rows.append(("   decoder branches alone", graphed(lambda: dec._branches(outs, ff))))
+        (tokens,), br = gd()
+        b, _, c = tokens.shape
+        fx = tokens.reshape(b, 7, 7, c).permute(0, 3, 1, 2)
+        rows.append(("decoder trunk", graphed(lambda: dec._trunk(fx, br))))
+    for n, ms in rows:
+        print(f"{n:32s} {ms:7.3f} ms")
+    print(f"{'SUM of top-level phases':32s} {sum(ms for n, ms in rows if not n.startswith(' ')):7.3f} ms")

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--math", choices=["fp32", "bf16", "bf16x3"], default="bf16")
     ap.add_argument("--bucket-mb", type=int, default=64)
+    ap.add_argument("--train-mode", action="store_true", help=".train(): stochastic depth on (masks from torch's graph-safe generator)")
     ap.add_argument("--graph", action="store_true", help="replay the step from hipGraphs (forward+backward | AdamW), all-reduce eager between them")
     args = ap.parse_args()
     world, rank, local = (int(os.environ.get(k, d)) for k, d in (("WORLD_SIZE", "1"), ("RANK", "0"), ("LOCAL_RANK", "0")))
@@ -41,6 +42,8 @@ def main():
     ops.set_matrix_math(args.math)
     enc = fill_module_(Encoder(num_frames=args.frames)).eval().to(dev)          # same weights on every rank (deterministic fill)
     dec = fill_module_(Decoder(input_token_temporal_dims=[1, 1, args.frames])).eval().to(dev)
+    if args.train_mode:
+        enc.train(); dec.train()
     opts = build_optimizers(enc, dec, lr_cnn=1e-6, lr=1e-5, lr_cva=1e-6, weight_decay=1e-4, weight_decay_cnn=1e-4)
     x = seeded_randn(100 + rank, args.batch, args.frames, 3, 224, 224).to(dev)
     target = (torch.rand(args.batch, 1, 224, 224, generator=torch.Generator().manual_seed(7 + rank)) < 0.1).float().to(dev)
@@ -86,7 +89,7 @@ def main():
     if rank == 0:
         print(json.dumps({"metric": "train clips/s (fwd + loss + bwd + grad all-reduce + AdamW)", "value": round(args.batch * world * args.steps / dt, 3),
                           "unit": "clips/s", "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "graph": bool(args.graph), "micro_batch": args.batch,
-                          "frames": args.frames, "math": args.math, "backend": backend, "loss": [round(float(v), 5) for v in loss3],
+                          "frames": args.frames, "math": args.math, "train_mode": bool(args.train_mode), "backend": backend, "loss": [round(float(v), 5) for v in loss3],
                           "replicas_identical_after_steps": same}))
     if world > 1:
         dist.destroy_process_group()
