@@ -53,6 +53,41 @@ extern "C" {
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);
 
+/* ---- SwinDAttention with the index work folded into its GEMMs (round 3; csrc/cva_fused.hip) ----
+ * kv = [proj_k | proj_v](grid_sample(x2, pos)) (deform:353-362) in ONE launch: the bilinear sampling (align_corners=True, zeros
+ * padding, per-group positions, kv window i pairs with q window i mod nq) is the A-operand loader of the projection; the sampled
+ * map is never written.  x2 (B, Hs2*W, C) raster (already through `pre`), pos (nq,3,49,2) from mumpy_deform_offsets_fwd,
+ * Wkv (2C, C) = [W_k; W_v], bkv (2C), kv (B * Hs2/7 * W/7, 49, 2C).  C in {96,192,384,768}. */
+int mumpy_deform_sample_kv_fwd(const float* x2, const float* pos, const float* Wkv, const float* bkv, float* kv, int B, int Hs2,
+                               int W, int C, int nq, void* stream);
+
+/* out = x1 + x1[window order] + reshape_(C,49)->(49,C)(proj_out(o)) (deform:402-403; mTVE:138,285-286) in ONE launch: the
+ * projection is computed transposed so that the un-permuted reshape lands on coalesced stores and the caller's two residual
+ * terms ride in the epilogue.  o (B * H/7 * W/7, 49, C) from mumpy_deform_attention_fwd, Wout (C, C), bout (C), x1 / out
+ * (B, H*W, C) raster; out must not alias x1.  Replaces a mumpy_linear_fwd + mumpy_deform_combine_fwd pair. */
+int mumpy_deform_out_combine_fwd(const float* o, const float* Wout, const float* bout, const float* x1, float* out, int B, int H,
+                                 int W, int C, void* stream);
+
+/* ---- data-movement / wiring kernels of the decoder and the encoder tail (round 3: formerly ATen launches) ----
+ * 2x2 average pooling, stride 2 (the nn.AvgPool2d(2) of decoder.py:149-178's frequency blocks): x (B,H,W,C) NHWC -- or, nchw_in
+ * = 1, (B,C,H,W) contiguous as FAF emits it (dct:79) -- -> out (B,H/2,W/2,Cpad) NHWC with channels [C,Cpad) zero (the
+ * implicit-GEMM convolution wants Cin % 32 == 0).  H, W even; Cpad % 4 == 0; NHWC input: C % 4 == 0. */
+int mumpy_avgpool2_pad_nhwc_fwd(const float* x, float* out, int B, int H, int W, int C, int Cpad, int nchw_in, void* stream);
+
+/* rows x cols floats between row pitches (floats): a channel slice of a concatenated NHWC map (decoder.py:197,210,213) or the
+ * first three temporal slices of the global tokens (mTVE:745).  cols, pitches % 4 == 0. */
+int mumpy_copy_rows_fwd(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows, int cols, void* stream);
+
+/* merge_views_along_channel_axis + the (b t n c) -> (b n) t c regrouping in front of the global embedding (mTVE:710-718,739):
+ * view k is (B, t_k * n, C_k), frames stacked on rows, t_k in {1, T}; out ((B n T), C1+C2+C3) row (b, site, t) =
+ * [v1[b, t or 0, site] | v2[...] | v3[...]]. */
+int mumpy_merge_views_fwd(const float* v1, const float* v2, const float* v3, float* out, int B, int T, int n, int C1, int C2,
+                          int C3, int t1, int t2, int t3, void* stream);
+
+/* decoder.py:198-205: z = gcn * freq + PixelShuffle(2)(g * f); g, f (B,h,w,4C), gcn, freq, z (B,2h,2w,C), NHWC. */
+int mumpy_trunk_head_fwd(const float* g, const float* f, const float* gcn, const float* freq, float* z, int B, int h, int w, int C,
+                         void* stream);
+
 /* ---- LayerNorm over the last dim (nn.LayerNorm, eps 1e-5, affine)  — swin:266,305; blocks:86-88 ----
  * x, y: (rows, C) token-major; y may alias x.  C % 4 == 0, C <= 4096. */
 int mumpy_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y,

@@ -183,7 +183,15 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
 #pragma unroll
     for (int t = 0; t < 9; ++t) wr[t] = *reinterpret_cast<const f32x4*>(w + t * 32 + 4 * sub);
     const float b0 = bias[0];
-    for (int64_t pix = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3; pix < npix; pix += ((int64_t)gridDim.x * 256) >> 3) {
+    // Workgroups are dealt round-robin over the 8 XCDs, each with its own L2.  With pixel runs dealt in launch order the rows
+    // above and below a run were fetched by OTHER XCDs, so every tap row came from beyond L2 again: 156 MB read for a 51 MB map
+    // (PMC, profiles/r02_pmc_bench_traffic.md).  Renumbered XCD-major, an XCD sweeps one contiguous band of image rows and finds
+    // its neighbour rows in its own L2.
+    const unsigned G = gridDim.x, xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+    const int64_t vb = (xcd < r8 ? (int64_t)xcd * (q8 + 1) : (int64_t)r8 * (q8 + 1) + (int64_t)(xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int64_t per = (npix + G - 1) / G;                      // contiguous pixels per workgroup
+    const int64_t pend = (vb + 1) * per < npix ? (vb + 1) * per : npix;
+    for (int64_t pix = vb * per + (threadIdx.x >> 3); pix < pend; pix += 32) {
         const int xx = (int)(pix % W);
         const int yy = (int)((pix / W) % H);
         float acc = 0.f;
@@ -241,7 +249,176 @@ __global__ __launch_bounds__(256) void final_conv_wide_kernel(const float* __res
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Small data-movement / wiring kernels of the decoder and of the encoder tail (round 3: these were ATen launches --
+// avg_pool2d, cat, strided copy_, mul, add, PixelShuffle -- 19 per forward).
+
+// 2x2 average pooling (nn.AvgPool2d(2, stride=2) of the frequency blocks, decoder.py:149-178) into an NHWC map whose channel count
+// is padded with zeros to Cpad (the implicit-GEMM convolution wants Cin % 32 == 0; only the 9-channel DCT input needs it).
+// NCHW_IN: x is (B, C, H, W) contiguous (the FAF output, dct:79) -- lanes run along x so a plane row is read coalesced.
+template <bool NCHW_IN>
+__global__ __launch_bounds__(256) void avgpool2_pad_kernel(const float* __restrict__ x, float* __restrict__ out, int H, int W, int C,
+                                                           int Cpad, int64_t total) {
+    const int Ho = H >> 1, Wo = W >> 1;
+    if (NCHW_IN) {
+        // thread = output pixel; writes Cpad floats (C <= 32 here)
+        for (int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (int64_t)gridDim.x * 256) {
+            const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+            const int64_t b = pix / ((int64_t)Wo * Ho);
+            const float* p = x + (b * C * H + 2 * oy) * (int64_t)W + 2 * ox;
+            float* o = out + pix * Cpad;
+            for (int c0 = 0; c0 < Cpad; c0 += 4) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = c0 + e;
+                    if (c < C) {
+                        const float* q = p + (int64_t)c * H * W;
+                        v[e] = ((q[0] + q[1]) + (q[W] + q[W + 1])) * 0.25f;       // ATen's avg_pool2d sums the window, then divides
+                    }
+                }
+                *reinterpret_cast<f32x4*>(o + c0) = v;
+            }
+        }
+    } else {
+        const int c4n = Cpad >> 2;                              // thread = (output pixel, channel quad)
+        for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total * c4n; idx += (int64_t)gridDim.x * 256) {
+            const int c4 = (int)(idx % c4n);
+            const int64_t pix = idx / c4n;
+            const int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+            const int64_t b = pix / ((int64_t)Wo * Ho);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (4 * c4 < C) {
+                const float* p = x + ((b * H + 2 * oy) * (int64_t)W + 2 * ox) * C + 4 * c4;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p), bq = *reinterpret_cast<const f32x4*>(p + C);
+                const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C), d = *reinterpret_cast<const f32x4*>(p + (int64_t)W * C + C);
+                v = ((a + bq) + (c + d)) * 0.25f;
+            }
+            *reinterpret_cast<f32x4*>(out + pix * Cpad + 4 * c4) = v;
+        }
+    }
+}
+
+// rows x cols floats from rows of pitch src_stride to rows of pitch dst_stride (channel slices of concatenated NHWC maps:
+// decoder.py:197,210,213; the first three temporal slices of the global tokens, mTVE:745)
+__global__ __launch_bounds__(256) void copy_rows_kernel(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst,
+                                                        int64_t dst_stride, int64_t rows, int c4n) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * c4n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / c4n;
+        const int c4 = (int)(idx - r * c4n);
+        *reinterpret_cast<f32x4*>(dst + r * dst_stride + 4 * c4) = *reinterpret_cast<const f32x4*>(src + r * src_stride + 4 * c4);
+    }
+}
+
+// channel merge of the three views for the global embedding (mTVE:710-718, 739): out row (b, site, t) =
+// [v1[b, t1 == T ? t : 0, site, :C1] | v2 ... | v3 ...]; view k is (B, t_k * n, C_k) with its frames stacked on rows.
+struct MergeArgs { const float* v[3]; int c[3]; int t[3]; };
+__global__ __launch_bounds__(256) void merge_views_kernel(MergeArgs a, float* __restrict__ out, int T, int n, int64_t rows) {
+    const int ctot = a.c[0] + a.c[1] + a.c[2], c4n = ctot >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < rows * c4n; idx += (int64_t)gridDim.x * 256) {
+        const int64_t r = idx / c4n;                            // (b, site, t)
+        int c = 4 * (int)(idx - r * c4n);
+        const int t = (int)(r % T);
+        const int64_t bs = r / T;
+        const int site = (int)(bs % n);
+        const int64_t b = bs / n;
+        const int k = c < a.c[0] ? 0 : (c < a.c[0] + a.c[1] ? 1 : 2);
+        c -= k == 0 ? 0 : (k == 1 ? a.c[0] : a.c[0] + a.c[1]);
+        const int tk = a.t[k] == 1 ? 0 : t;
+        const float* s = a.v[k] + ((b * a.t[k] + tk) * n + site) * (int64_t)a.c[k] + c;
+        *reinterpret_cast<f32x4*>(out + idx * 4) = *reinterpret_cast<const f32x4*>(s);
+    }
+}
+
+// decoder.py:198-205: z = gcn1 * freq3 + PixelShuffle(2)(g * f) with g, f (B,h,w,4C) and gcn1, freq3, z (B,2h,2w,C), all NHWC.
+// PixelShuffle: out[c, 2y+i, 2x+j] = in[4c + 2i + j, y, x].
+__global__ __launch_bounds__(256) void trunk_head_kernel(const float* __restrict__ g, const float* __restrict__ f,
+                                                         const float* __restrict__ gcn, const float* __restrict__ fr,
+                                                         float* __restrict__ z, int h, int w, int C, int64_t total) {
+    const int c4n = C >> 2;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(idx % c4n);
+        const int64_t pix = idx / c4n;
+        const int ox = (int)(pix % (2 * w)), oy = (int)((pix / (2 * w)) % (2 * h));
+        const int64_t b = pix / ((int64_t)4 * h * w);
+        const int sub = 2 * (oy & 1) + (ox & 1);
+        const float* gp = g + ((b * h + (oy >> 1)) * (int64_t)w + (ox >> 1)) * (4 * C);
+        const float* fp = f + (gp - g);
+        f32x4 ps;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ci = 4 * (4 * c4 + e) + sub;
+            ps[e] = gp[ci] * fp[ci];
+        }
+        const f32x4 a = *reinterpret_cast<const f32x4*>(gcn + idx * 4), bq = *reinterpret_cast<const f32x4*>(fr + idx * 4);
+        *reinterpret_cast<f32x4*>(z + idx * 4) = a * bq + ps;
+    }
+}
+
 }  // namespace
+
+extern "C" int mumpy_avgpool2_pad_nhwc_fwd(const float* x, float* out, int B, int H, int W, int C, int Cpad, int nchw_in,
+                                           void* stream) {
+    MUMPY_REQUIRE(x && out, MUMPY_ENULL, "avgpool2: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(out), MUMPY_EALIGN, "avgpool2: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && Cpad >= C && Cpad % 4 == 0, MUMPY_EINVAL,
+                  "avgpool2: bad shape (%d,%d,%d,%d) -> Cpad %d", B, H, W, C, Cpad);
+    MUMPY_REQUIRE(nchw_in || C % 4 == 0, MUMPY_EINVAL, "avgpool2: an NHWC input needs C %% 4 == 0 (got %d)", C);
+    const int64_t total = (int64_t)B * (H / 2) * (W / 2);
+    int64_t grid = ((nchw_in ? total : total * (Cpad / 4)) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    if (nchw_in) hipLaunchKernelGGL(avgpool2_pad_kernel<true>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, out, H, W, C, Cpad, total);
+    else hipLaunchKernelGGL(avgpool2_pad_kernel<false>, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, out, H, W, C, Cpad, total);
+    MUMPY_CHECK_LAUNCH("avgpool2_pad");
+    return 0;
+}
+
+extern "C" int mumpy_copy_rows_fwd(const float* src, int64_t src_stride, float* dst, int64_t dst_stride, int64_t rows, int cols,
+                                   void* stream) {
+    if (rows == 0) return 0;
+    MUMPY_REQUIRE(src && dst, MUMPY_ENULL, "copy_rows: null pointer");
+    MUMPY_REQUIRE(aligned16(src) && aligned16(dst) && src_stride % 4 == 0 && dst_stride % 4 == 0 && cols % 4 == 0, MUMPY_EALIGN,
+                  "copy_rows: pointers, strides and the column count must be multiples of 16 bytes");
+    MUMPY_REQUIRE(rows > 0 && cols > 0 && src_stride >= cols && dst_stride >= cols, MUMPY_EINVAL, "copy_rows: bad sizes");
+    int64_t grid = (rows * (cols / 4) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), src, src_stride, dst, dst_stride, rows, cols / 4);
+    MUMPY_CHECK_LAUNCH("copy_rows");
+    return 0;
+}
+
+extern "C" int mumpy_merge_views_fwd(const float* v1, const float* v2, const float* v3, float* out, int B, int T, int n, int C1,
+                                     int C2, int C3, int t1, int t2, int t3, void* stream) {
+    MUMPY_REQUIRE(v1 && v2 && v3 && out, MUMPY_ENULL, "merge_views: null pointer");
+    MUMPY_REQUIRE(aligned16(v1) && aligned16(v2) && aligned16(v3) && aligned16(out), MUMPY_EALIGN, "merge_views: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && T > 0 && n > 0 && C1 > 0 && C2 > 0 && C3 > 0 && C1 % 4 == 0 && C2 % 4 == 0 && C3 % 4 == 0, MUMPY_EINVAL,
+                  "merge_views: bad sizes");
+    MUMPY_REQUIRE((t1 == 1 || t1 == T) && (t2 == 1 || t2 == T) && (t3 == 1 || t3 == T), MUMPY_EINVAL,
+                  "merge_views: a view's temporal length must be 1 or T=%d (got %d,%d,%d; mTVE:717 repeats by T / t)", T, t1, t2, t3);
+    MergeArgs a;
+    a.v[0] = v1; a.v[1] = v2; a.v[2] = v3; a.c[0] = C1; a.c[1] = C2; a.c[2] = C3; a.t[0] = t1; a.t[1] = t2; a.t[2] = t3;
+    const int64_t rows = (int64_t)B * n * T;
+    int64_t grid = (rows * ((C1 + C2 + C3) / 4) + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(merge_views_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a, out, T, n, rows);
+    MUMPY_CHECK_LAUNCH("merge_views");
+    return 0;
+}
+
+extern "C" int mumpy_trunk_head_fwd(const float* g, const float* f, const float* gcn, const float* freq, float* z, int B, int h,
+                                    int w, int C, void* stream) {
+    MUMPY_REQUIRE(g && f && gcn && freq && z, MUMPY_ENULL, "trunk_head: null pointer");
+    MUMPY_REQUIRE(aligned16(g) && aligned16(f) && aligned16(gcn) && aligned16(freq) && aligned16(z), MUMPY_EALIGN,
+                  "trunk_head: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && h > 0 && w > 0 && C > 0 && C % 4 == 0, MUMPY_EINVAL, "trunk_head: bad shape");
+    const int64_t total = (int64_t)B * 4 * h * w * (C / 4);
+    int64_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(trunk_head_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), g, f, gcn, freq, z, h, w, C, total);
+    MUMPY_CHECK_LAUNCH("trunk_head");
+    return 0;
+}
 
 extern "C" int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias, float* logits, uint8_t* mask,
                                     int B, int H, int W, int C, float thr, void* stream) {
@@ -252,6 +429,10 @@ extern "C" int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const f
     const int64_t npix = (int64_t)B * H * W;
     int64_t grid = (npix * 8 + 255) / 256;
     if (grid > 8192) grid = 8192;
+    if (C == 32) {          // contiguous 128-pixel runs per workgroup (four 32-pixel passes), renumbered XCD-major in the kernel
+        grid = (npix + 127) / 128;
+        if (grid > 65536) grid = 65536;
+    }
     if (C == 32)
         hipLaunchKernelGGL(final_conv_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, bias, logits,
                            mask, H, W, npix, thr);

@@ -19,10 +19,12 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
                                                              const float* __restrict__ ln_b,
                                                              const float* __restrict__ pw_w, float* __restrict__ pos,
                                                              int H, int W, int C, int nWx, int nWf) {
-    __shared__ __attribute__((aligned(16))) float sm[2 * WT * Cg + 25 * Cg];   // static: up to 126 KB at Cg = 256
-    float* tile = sm;             // [49][Cg]
-    float* conv = sm + WT * Cg;   // [49][Cg]
-    float* wsm = sm + 2 * WT * Cg;   // [Cg][25] depthwise taps
+    constexpr int CP = Cg + 4;      // conv row pitch: 16 pixels x 4 lanes read 64 distinct banks in the LayerNorm phase
+    __shared__ __attribute__((aligned(16))) float sm[WT * Cg + WT * CP + 25 * Cg + 4 * Cg];   // static: up to 131 KB at Cg = 256
+    float* tile = sm;                       // [49][Cg]
+    float* conv = sm + WT * Cg;             // [49][CP]
+    float* wsm = conv + WT * CP;            // [Cg][25] depthwise taps
+    float* par = wsm + 25 * Cg;             // LayerNorm gamma | beta | 1x1 weights (dy) | (dx)
     const int bw = blockIdx.x, g = blockIdx.y;
     const int b = bw / nWf, n = bw - b * nWf;
     const int wy = n / nWx, wx = n - wy * nWx;
@@ -35,10 +37,14 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
         const int tok = window_token(wy, wx, p, H, W, 0);
         *reinterpret_cast<f32x4*>(tile + p * Cg + 4 * c4) = *reinterpret_cast<const f32x4*>(qb + (int64_t)tok * C + 4 * c4);
     }
-    // the group's 25 taps per channel: coalesced into LDS first.  (Each thread used to gather its 25 taps from global memory
-    // at a 100-byte lane stride: ~50 cache lines per load instruction, 25 of them per thread -- the texture-address path
-    // of a CU serialised the six resident blocks for 24-44 us per launch, most of the kernel's time.)
+    // the group's 25 taps per channel and the per-channel parameters of the LayerNorm / 1x1 stage: coalesced into LDS
     for (int idx = tid; idx < 25 * Cg; idx += 256) wsm[idx] = dw_w[idx];
+    for (int idx = tid; idx < Cg; idx += 256) {
+        par[idx] = ln_g[idx];
+        par[Cg + idx] = ln_b[idx];
+        par[2 * Cg + idx] = pw_w[idx];
+        par[3 * Cg + idx] = pw_w[Cg + idx];
+    }
     // 256 % Cg == 0 (Cg in {32,64,128,256}): a thread keeps one channel for all its pixels
     const int cc = tid % Cg;
     const float breg = dw_b[cc];
@@ -49,8 +55,7 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
     for (int p = tid / Cg; p < WT; p += 256 / Cg) {
         const int py = p / WS, px = p - py * WS;
         // branch-free taps: out-of-window taps read the centre pixel and contribute fmaf(0, w, acc) == acc, so the 25 LDS
-        // reads of a pixel are independent and issue back to back (the `continue` form serialised them behind branches:
-        // 66 us for the 24 blocks of the widest call, all of it LDS latency)
+        // reads of a pixel are independent and issue back to back
         float acc = breg;
 #pragma unroll
         for (int dy = 0; dy < 5; ++dy) {
@@ -66,41 +71,40 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
                 acc = fmaf(ok ? t : 0.f, wreg[dy * 5 + dx], acc);
             }
         }
-        conv[p * Cg + cc] = acc;
+        conv[p * CP + cc] = acc;
     }
     __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
-    for (int p = wave; p < WT; p += 4) {
-        float v[4];
+    // LayerNorm over the group's channels -> GELU -> 1x1 conv to (dy, dx): FOUR lanes per pixel, each walking a quarter of the
+    // channels (lane qd takes channels qd, qd + 4, ...), partial sums combined with two quad shuffles (DPP).  The first version
+    // gave a whole wave to a pixel and reduced across 64 lanes four times per pixel: 13 pixels x 24 cross-lane steps per wave
+    // were ~2/3 of the kernel's 24-44 us.
+    const int p = tid >> 2, qd = tid & 3;
+    if (p < WT) {
+        const float* cv = conv + p * CP;
         float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = lane + 64 * i;
-            v[i] = (ch < Cg) ? conv[p * Cg + ch] : 0.f;
-            s += v[i];
-        }
-        const float mean = wave_sum(s, 64) / (float)Cg;
+#pragma unroll 8
+        for (int ch = qd; ch < Cg; ch += 4) s += cv[ch];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)Cg;
         float qq = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = lane + 64 * i;
-            const float d = (ch < Cg) ? v[i] - mean : 0.f;
-            qq += d * d;
-        }
-        const float rstd = rsqrtf(wave_sum(qq, 64) / (float)Cg + 1e-5f);
+#pragma unroll 8
+        for (int ch = qd; ch < Cg; ch += 4) { const float d = cv[ch] - mean; qq = fmaf(d, d, qq); }
+        qq += __shfl_xor(qq, 1);
+        qq += __shfl_xor(qq, 2);
+        const float rstd = rsqrtf(qq / (float)Cg + 1e-5f);
         float oy = 0.f, ox = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ch = lane + 64 * i;
-            if (ch < Cg) {
-                const float a = gelu_erf((v[i] - mean) * rstd * ln_g[ch] + ln_b[ch]);
-                oy = fmaf(a, pw_w[ch], oy);
-                ox = fmaf(a, pw_w[Cg + ch], ox);
-            }
+#pragma unroll 4
+        for (int ch = qd; ch < Cg; ch += 4) {
+            const float a = gelu_erf((cv[ch] - mean) * rstd * par[ch] + par[Cg + ch]);
+            oy = fmaf(a, par[2 * Cg + ch], oy);
+            ox = fmaf(a, par[3 * Cg + ch], ox);
         }
-        oy = wave_sum(oy, 64);
-        ox = wave_sum(ox, 64);
-        if (lane == 0) {
+        oy += __shfl_xor(oy, 1);
+        oy += __shfl_xor(oy, 2);
+        ox += __shfl_xor(ox, 1);
+        ox += __shfl_xor(ox, 2);
+        if (qd == 0) {
             const int py = p / WS, px = p - py * WS;
             const float ry = ((0.5f + (float)py) / 7.0f) * 2.0f - 1.0f;
             const float rx = ((0.5f + (float)px) / 7.0f) * 2.0f - 1.0f;

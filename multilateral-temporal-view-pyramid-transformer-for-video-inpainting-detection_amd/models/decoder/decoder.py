@@ -124,11 +124,9 @@ class Decoder(nn.Module):
         pad = (-cin) % 32
         w = self._cached(("w", id(conv)), (conv.weight,),
                          lambda: F.pad(conv.weight.permute(0, 2, 3, 1), (0, pad)).contiguous())
-        if pad:
-            b, _, h, wd = x.shape
-            xp = torch.zeros(b, h, wd, cin + pad, device=x.device, dtype=torch.float32)
-            xp[..., :cin] = x.permute(0, 2, 3, 1)
-            x = xp.permute(0, 3, 1, 2)
+        if pad and x.shape[1] != cin + pad:
+            raise RuntimeError(f"Decoder._conv: a {cin}-channel convolution takes its input zero-padded to {cin + pad} channels "
+                               "(ops.avgpool2_pad does it for the frequency branch)")
         return ops.conv2d_nhwc(x, w, conv.bias, residual=residual)
 
     def _gcm(self, m, x):                                              # x_l + x_r fused into the last conv's epilogue
@@ -166,8 +164,11 @@ class Decoder(nn.Module):
         y, g = self._gn(y, gn)
         return ops.gn_apply_resample(y, g, act=ops.ACT_RELU)
 
-    def _freq(self, seq, x):
-        x = self._conv(F.avg_pool2d(x, 2), seq[1])
+    def _freq(self, seq, x, nchw_in=False):
+        """AvgPool2d(2) -> conv3x3 -> GroupNorm -> Sigmoid (decoder.py:149-178).  The pooling kernel also pads the channels to
+        the multiple of 32 the implicit-GEMM convolution wants and reads the FAF output in its NCHW layout."""
+        cin = seq[1].weight.shape[1]
+        x = self._conv(ops.avgpool2_pad(x, cin + (-cin) % 32, nchw_in=nchw_in), seq[1])
         x, g = self._gn(x, seq[2])
         return ops.gn_apply_resample(x, g, act=ops.ACT_SIGMOID)
 
@@ -189,7 +190,7 @@ class Decoder(nn.Module):
         b, dev = ffinfo.shape[0], ffinfo.device
 
         def freq_chain():
-            f0 = self._freq(self.decoder_frequency_0, ffinfo.contiguous(memory_format=torch.channels_last))
+            f0 = self._freq(self.decoder_frequency_0, ffinfo, nchw_in=ffinfo.is_contiguous())
             f1 = self._freq(self.decoder_frequency_1, f0)
             f2 = self._freq(self.decoder_frequency_2, f1)
             f3 = self._freq(self.decoder_frequency_3, f2)
@@ -208,13 +209,13 @@ class Decoder(nn.Module):
 
         def pyr2():
             cat2 = ops.empty_nhwc(b, 512, 14, 14, dev)                 # [rgb3 | up2(rgb4)]          (decoder.py:210)
-            cat2[:, :256] = rgb3
+            ops.set_channels(cat2, 0, rgb3)
             self._up(rgb4, 2, out=cat2, out_coff=256)
             return [self._gcm(self.gcm3, self._seb(self.seb2, rgb2, cat2))]
 
         def pyr3():
             cat3 = ops.empty_nhwc(b, 768, 28, 28, dev)                 # [rgb2 | up2(rgb3) | up4(rgb4)] (decoder.py:213)
-            cat3[:, :256] = rgb2
+            ops.set_channels(cat3, 0, rgb2)
             self._up(rgb3, 2, out=cat3, out_coff=256)
             self._up(rgb4, 4, out=cat3, out_coff=512)
             return [self._gcm(self.gcm4, self._seb(self.seb3, rgb1, cat3))]
@@ -227,9 +228,14 @@ class Decoder(nn.Module):
         """gcm1 on [rgb4 | final tokens] and the sequential decoder_2..5 trunk -> x_feats (B,32,224,224), NHWC memory."""
         freq0, freq1, freq2, freq3, freq4 = br["freq"]
         gcn1, gcn2, gcn3 = br["gcn"]
-        x = x.contiguous(memory_format=torch.channels_last)
-        out1 = self.ecre(self._gcm(self.gcm1, torch.cat([br["rgb4"], x], dim=1)) * freq4)
-        z = self._dec(self.decoder_2, gcn1 * freq3 + out1, ops.EP_ADD_MUL, gcn2, freq2)     # = decoder_3's input
+        rgb4 = br["rgb4"]
+        b, c4, h, w = rgb4.shape
+        cat1 = ops.empty_nhwc(b, c4 + x.shape[1], h, w, rgb4.device)                        # [rgb4 | final tokens] (decoder.py:197)
+        ops.set_channels(cat1, 0, rgb4)
+        ops.set_channels(cat1, c4, x)                   # x: dense NHWC or the strided 3-of-T slice view of the global tokens
+        # PixelShuffle(2)(gcm1(...) * freq4), then gcn1 * freq3 + that: one kernel (decoder.py:198-205)
+        z = ops.trunk_head(self._gcm(self.gcm1, cat1), freq4, gcn1, freq3)
+        z = self._dec(self.decoder_2, z, ops.EP_ADD_MUL, gcn2, freq2)                       # = decoder_3's input
         z = self._dec(self.decoder_3, z, ops.EP_ADD_MUL, gcn3, freq1)                       # = decoder_4's input
         z = self._dec(self.decoder_4, z, ops.EP_MUL, freq0)                                 # = decoder_5's input
         return self._dec(self.decoder_5, z, mean4=True)                                     # DAP folded in

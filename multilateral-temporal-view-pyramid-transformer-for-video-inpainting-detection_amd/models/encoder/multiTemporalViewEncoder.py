@@ -92,9 +92,8 @@ class CrossSwinBlock(nn.Module):
         if not self.last_view:
             hs2 = x2.shape[1] // w
             x2p = ops.linear(x2, self.pre.weight, self.pre.bias)                    # per-token, raster (mTVE:283)
-            yt = self.cva.crossattn.attend_raster(x1, x2p, b, hs1, w, hs2, prep)
             # x1 + [x1 in window order] + [scrambled proj_out]  (mTVE:138, 285-286; deform:403)
-            x1 = ops.deform_combine(x1, yt, b, hs1, w, c1)
+            x1 = self.cva.crossattn.attend_combine(x1, x2p, b, hs1, w, hs2, prep)
         if ops.storage() == "bf16":
             return self.mlp.forward_bf16(ops.layernorm_bf16(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), x1)
         return self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1)
@@ -317,15 +316,23 @@ class ThreeViewSwinTransformer(nn.Module):
             [lambda: (self.faf.forward_frame(x, 1),), lambda: self.layers(self.tokenize(x))], [(x,), (x,)])
         return views, [[v.unsqueeze(1) for v in stage] for stage in stage_out], ffinfo
 
-    def forward_global(self, views):
-        """Channel-merge of the views + the 12 temporal ViT blocks -> tokens (B,49,2304)."""
+    def forward_global(self, views, dense=True):
+        """Channel-merge of the views + the 12 temporal ViT blocks -> tokens (B,49,2304).
+        dense=False (the fused pipeline): the result is the strided view of the blocks' output -- the first three temporal
+        slices of a site are 2304 contiguous floats of its T * 768 -- and the decoder copies it straight into its
+        concatenated map; dense=True materialises it (one strided row copy)."""
         b = views[0].shape[0]
-        g = self.merge_views_along_channel_axis(views)                         # (B,T,49,2560)
-        t = g.shape[1]
-        g = g.permute(0, 2, 1, 3).reshape(b * 49, t, g.shape[-1])              # one T-token sequence per site
+        t = max(self.input_token_temporal_dims)
+        g = ops.merge_views(views, self.input_token_temporal_dims).reshape(b * 49, t, -1)     # one T-token sequence per site
         g = ops.linear(g, self.globalembedding.weight, self.globalembedding.bias)
-        g = self.globalblocks(g).reshape(b, 49, t, 768)
-        return g[:, :, :3].reshape(b, 49, 3 * 768)                             # frames 0,1,2 on channels (mTVE:745)
+        g = self.globalblocks(g).reshape(b, 49, t * 768)
+        if t < 3:
+            raise RuntimeError("ThreeViewSwinTransformer: the encoder tail takes temporal slices 0,1,2 (mTVE:745): T >= 3")
+        if not dense:
+            return g[:, :, :3 * 768]                                           # frames 0,1,2 on channels (mTVE:745)
+        out = torch.empty(b, 49, 3 * 768, device=g.device, dtype=torch.float32)
+        ops.copy_rows(g, t * 768, out, 3 * 768, b * 49, 3 * 768)
+        return out
 
     def forward(self, x):
         """x (B,T,3,224,224) -> (tokens (B,49,2304), view_x[4][3] of (B,1,L,C), dct (B,9,224,224))."""

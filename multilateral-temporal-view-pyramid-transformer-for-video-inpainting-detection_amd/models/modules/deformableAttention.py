@@ -15,6 +15,14 @@ from models.modules.layers import Derived
 from mumpy_hip import ops
 
 
+# Round 3: the index work around two of the module's GEMMs rides inside them (csrc/cva_fused.hip).  Switchable per kernel for
+# A/B runs (MUMPY_CVA_FUSED=0 / "kv" / "out" / 1); the split-precision and bf16 modes keep the unfused route (their operand
+# modes live in the generic GEMM).
+import os as _os
+_f = _os.environ.get("MUMPY_CVA_FUSED", "1")
+FUSED = {"sample_kv": _f in ("1", "kv"), "out_combine": _f in ("1", "out")}
+
+
 class LayerNormProxy(nn.Module):
     """LayerNorm over channels of a (B,C,H,W) map; inside the HIP offsets kernel this is fused, the module only
     holds the parameters (key `...conv_offset.1.norm.*`)."""
@@ -75,6 +83,11 @@ class SwinDAttention(nn.Module):
     def _run(self, x1, x2, q_grid, kv_grid, prep=None):
         """q_grid = (b, h, w): x1 is (b, h*w, C) raster;  kv_grid = (b2, hs2, w2): x2 is (b2, hs2*w2, C) raster.
         Returns proj_out output Yt (nq, 49, C): window-major, token-major, i.e. BEFORE the deform:403 reshape."""
+        o = self._attend(x1, x2, q_grid, kv_grid, prep)
+        return ops.linear(o, self.proj_out.weight, self.proj_out.bias)
+
+    def _attend(self, x1, x2, q_grid, kv_grid, prep=None):
+        """Everything up to (not including) proj_out: -> o (nq,49,C), the attention output summed over the r-tuples."""
         c = self.nc
         b, h, w = q_grid
         b2, hs2, w2 = kv_grid
@@ -83,14 +96,26 @@ class SwinDAttention(nn.Module):
         if nkv % nq:
             raise RuntimeError(f"SwinDAttention: {nkv} kv windows is not a multiple of {nq} q windows")
         q, pos = prep if prep is not None else self._prep(x1, q_grid)
-        sampled = ops.deform_sample(x2, pos, b2, hs2, w2, c, nq)
         wkv = self._wkv.get((self.proj_k.weight, self.proj_v.weight),
                             lambda: torch.cat([self.proj_k.weight.reshape(c, c), self.proj_v.weight.reshape(c, c)], 0))
         bkv = self._bkv.get((self.proj_k.bias, self.proj_v.bias), lambda: torch.cat([self.proj_k.bias, self.proj_v.bias]))
-        kv = ops.linear(sampled, wkv, bkv)                                        # (nkv,49,2C)
+        if FUSED["sample_kv"] and ops.matrix_math() == "fp32" and ops.storage() == "fp32":
+            kv = ops.deform_sample_kv(x2, pos, wkv, bkv, b2, hs2, w2, c, nq)      # sampling = the projection's A loader
+        else:
+            sampled = ops.deform_sample(x2, pos, b2, hs2, w2, c, nq)
+            kv = ops.linear(sampled, wkv, bkv)                                    # (nkv,49,2C)
         pad = self._pad.get((self.proj_q.weight,), lambda: ops.pad_mask().to(x1.device))
-        o = ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)   # (nq,49,C)
-        return ops.linear(o, self.proj_out.weight, self.proj_out.bias)
+        return ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)   # (nq,49,C)
+
+    def attend_combine(self, x1, x2, b, h, w, hs2, prep=None):
+        """The cross block's use of the module (mTVE:283-286): x1 + x1[window order] + the scrambled attention output, i.e.
+        CVAModule's `x1w + D` laid out window-major and added to raster x1.  Fused form: proj_out, the un-permuted (C,49)->(49,C)
+        reshape and both residual terms are ONE launch (mumpy_deform_out_combine_fwd)."""
+        if FUSED["out_combine"] and ops.matrix_math() == "fp32" and ops.storage() == "fp32":
+            o = self._attend(x1, x2, (b, h, w), (b, hs2, w), prep)
+            return ops.deform_out_combine(o, self.proj_out.weight.reshape(self.nc, self.nc), self.proj_out.bias, x1, b, h, w, self.nc)
+        yt = self._run(x1, x2, (b, h, w), (b, hs2, w), prep)
+        return ops.deform_combine(x1, yt, b, h, w, self.nc)
 
     def attend_raster(self, x1, x2, b, h, w, hs2, prep=None):
         """Fused-block entry: x1 (B, h*w, C) q-side tokens, x2 (B, hs2*w, C) kv-side tokens (already through

@@ -29,11 +29,17 @@ SIGNATURES = {
                                          c_i, c_i, c_i, c_i, c_f],
     "mumpy_conv2d_nhwc_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_conv2d_workspace_bytes": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],
+    "mumpy_avgpool2_pad_nhwc_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_copy_rows_fwd": [c_f, c_l, c_f, c_l, c_l, c_i, c_f],
+    "mumpy_merge_views_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_trunk_head_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_final_conv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_window_attention_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_deform_offsets_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_sample_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_attention_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_deform_sample_kv_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_f],
+    "mumpy_deform_out_combine_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_deform_combine_fwd": [c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_faf_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_f],
     "mumpy_patch_embed_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],

@@ -317,6 +317,66 @@ def gn_apply_resample(x, gn=None, act=0, mean4=False, scale=1, align_corners=Fal
     return out
 
 
+def avgpool2_pad(x, cpad=None, nchw_in=False):
+    """2x2 average pooling -> logical (B,Cpad,H/2,W/2) with NHWC memory; channels [C,Cpad) are zero.  x: logical (B,C,H,W) with
+    NHWC memory, or (nchw_in) a contiguous NCHW tensor such as the FAF output."""
+    if nchw_in:
+        x = _chk(x, "x")
+    else:
+        x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    cpad = c if cpad is None else cpad
+    out = empty_nhwc(b, cpad, h // 2, w // 2, x.device)
+    _call("mumpy_avgpool2_pad_nhwc_fwd", _p(x), _p(out), b, h, w, c, cpad, 1 if nchw_in else 0, _stream(),
+          work=4.0 * (x.numel() + out.numel()))
+    return out
+
+
+def copy_rows(src, src_stride, dst, dst_stride, rows, cols):
+    """dst[r, :cols] = src[r, :cols] for r < rows, row pitches in floats; src / dst are tensors whose data_ptr() is row 0."""
+    if not (src.is_cuda and dst.is_cuda and src.dtype == dst.dtype == torch.float32):
+        raise RuntimeError("mumpy_hip: copy_rows needs float32 GPU tensors (there is no CPU path)")
+    _call("mumpy_copy_rows_fwd", src.data_ptr(), src_stride, dst.data_ptr(), dst_stride, rows, cols, _stream(), work=8.0 * rows * cols)
+    return dst
+
+
+def set_channels(dst, coff, src):
+    """dst[:, coff:coff+C] = src for logical (B,*,H,W) tensors with NHWC memory (a slice of a channel-concatenated map).
+    src may be any per-pixel-contiguous strided view whose pixels are uniformly pitched (e.g. the first 3 of 5 temporal slices)."""
+    b, c, h, w = src.shape
+    ctot = dst.shape[1]
+    if dst.stride() != (h * w * ctot, 1, w * ctot, ctot) or tuple(dst.shape[2:]) != (h, w) or dst.shape[0] != b:
+        raise RuntimeError("set_channels: dst must be a dense NHWC map of the same batch and size")
+    pitch = src.stride(3)
+    if src.stride(1) != 1 or src.stride(2) != w * pitch or (b > 1 and src.stride(0) != h * w * pitch) or pitch < c:
+        src = _nhwc(src, "src")
+        pitch = c
+    return copy_rows(src, pitch, dst[:, coff:], ctot, b * h * w, c)
+
+
+def merge_views(views, token_t, n=49):
+    """[(B, t_v * n, C_v)] x 3 -> ((B n T), sum C_v): the channel merge in front of the global embedding (mTVE:710-718, 739)."""
+    v = [_chk(t, "view") for t in views]
+    b = v[0].shape[0]
+    tmax = max(token_t)
+    out = torch.empty(b * n * tmax, sum(t.shape[2] for t in v), device=v[0].device, dtype=torch.float32)
+    _call("mumpy_merge_views_fwd", _p(v[0]), _p(v[1]), _p(v[2]), _p(out), b, tmax, n, v[0].shape[2], v[1].shape[2], v[2].shape[2],
+          token_t[0], token_t[1], token_t[2], _stream(), work=8.0 * out.numel())
+    return out
+
+
+def trunk_head(g, f, gcn, freq):
+    """gcn * freq + PixelShuffle(2)(g * f): g, f logical (B,4C,h,w), gcn, freq (B,C,2h,2w), all NHWC memory (decoder.py:198-205)."""
+    g, f, gcn, freq = _nhwc(g, "g"), _nhwc(f, "f"), _nhwc(gcn, "gcn"), _nhwc(freq, "freq")
+    b, c4, h, w = g.shape
+    c = c4 // 4
+    if f.shape != g.shape or tuple(gcn.shape) != (b, c, 2 * h, 2 * w) or freq.shape != gcn.shape:
+        raise RuntimeError("trunk_head: shape mismatch")
+    z = empty_nhwc(b, c, 2 * h, 2 * w, g.device)
+    _call("mumpy_trunk_head_fwd", _p(g), _p(f), _p(gcn), _p(freq), _p(z), b, h, w, c, _stream(), work=4.0 * (2 * g.numel() + 3 * z.numel()))
+    return z
+
+
 def add(a, b, out=None):
     a, b = _chk(a, "a"), _chk(b, "b")
     out = torch.empty_like(a) if out is None else out
@@ -405,6 +465,25 @@ def deform_sample(x2, pos, b, hs2, w, c, nq):
     out = torch.empty(nw2, 49, c, device=x2.device, dtype=torch.float32)
     _call("mumpy_deform_sample_fwd", _p(x2), _p(_chk(pos, "pos")), _p(out), b, hs2, w, c, nq, _stream(),
           work=4.0 * (2 * nw2 * 49 * c + nw2 * 3 * 49 * 2))       # bytes: read kv once, write sampled once, read offsets
+    return out
+
+
+def deform_sample_kv(x2, pos, wkv, bkv, b, hs2, w, c, nq):
+    """[proj_k | proj_v] of the bilinearly sampled kv windows in one launch (the sampled map is never materialised)."""
+    x2 = _chk(x2, "x2")
+    nw2 = b * (hs2 // 7) * (w // 7)
+    kv = torch.empty(nw2, 49, 2 * c, device=x2.device, dtype=torch.float32)
+    _call("mumpy_deform_sample_kv_fwd", _p(x2), _p(_chk(pos, "pos")), _p(_chk(wkv, "wkv")), _p(_chk(bkv, "bkv")), _p(kv), b, hs2, w, c, nq,
+          _stream(), work=2.0 * nw2 * 49 * 2 * c * c)
+    return kv
+
+
+def deform_out_combine(o, wout, bout, x1, b, h, w, c):
+    """x1 + x1[window order] + scrambled proj_out(o) in one launch (replaces linear + deform_combine)."""
+    o, x1 = _chk(o, "o"), _chk(x1, "x1")
+    out = torch.empty_like(x1)
+    _call("mumpy_deform_out_combine_fwd", _p(o), _p(_chk(wout, "wout")), _p(_chk(bout, "bout")), _p(x1), _p(out), b, h, w, c, _stream(),
+          work=2.0 * o.numel() * c)
     return out
 
 

@@ -28,10 +28,10 @@ def fused_forward(encoder, decoder, x, with_mask=False, thr=0.5):
     # current stream so that every nested fork is rooted on it (forking from a side stream inside hipGraph capture
     # crashed the ROCm 7.2 runtime)
     if FORK_GLOBAL_DECODER:
-        (tokens,), br = run_parallel([lambda: (base.forward_global(views),), lambda: decoder._branches(view_x, ffinfo)],
+        (tokens,), br = run_parallel([lambda: (base.forward_global(views, dense=False),), lambda: decoder._branches(view_x, ffinfo)],
                                      [views, flat + [ffinfo]])
     else:
-        tokens = base.forward_global(views)
+        tokens = base.forward_global(views, dense=False)      # strided 3-of-T view: the decoder copies it into its cat map
         br = decoder._branches(view_x, ffinfo)
     b, _, c = tokens.shape
     final_x = tokens.reshape(b, 7, 7, c).permute(0, 3, 1, 2)              # encoder.py:16-17

@@ -292,6 +292,76 @@ def test_decoder_tail_fusion():
     assert float(cat[:, :256].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("c,side,r", [(96, 14, 5), (96, 14, 1), (192, 14, 3), (384, 7, 5), (768, 7, 5), (768, 7, 1)])
+def test_deform_fused_gemms_match_the_unfused_kernels(c, side, r):
+    """csrc/cva_fused.hip against the launch sequences they replace, on the encoder's four widths, ragged tile edges (98 / 392 /
+    1960 rows) and positions that leave the window (zeros padding):
+      mumpy_deform_sample_kv_fwd   == mumpy_deform_sample_fwd -> mumpy_linear_fwd([W_k; W_v])
+      mumpy_deform_out_combine_fwd == mumpy_linear_fwd(proj_out) -> mumpy_deform_combine_fwd
+    Same fp32 products, different accumulation order: <= 2e-5 of the result's scale.  (The modules run the fused kernels by
+    default, so the reference goldens of test_swin_dattention / test_cross_swin_block / test_full_model_* pin them as well.)"""
+    b = 2
+    nq = b * (side // 7) ** 2
+    x2 = seeded_randn(50 + c, b, r * side * side, c).to(DEV)
+    pos = (torch.rand(nq, 3, 49, 2, generator=torch.Generator().manual_seed(51 + c)) * 2.6 - 1.3).to(DEV)     # some corners outside
+    wkv, bkv = (seeded_randn(52, 2 * c, c) / c ** 0.5).to(DEV), seeded_randn(53, 2 * c).to(DEV)
+    ref = ops.linear(ops.deform_sample(x2, pos, b, r * side, side, c, nq), wkv, bkv)
+    got = ops.deform_sample_kv(x2, pos, wkv, bkv, b, r * side, side, c, nq)
+    assert got.shape == ref.shape == (nq * r, 49, 2 * c)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+    o = seeded_randn(54 + c, nq, 49, c).to(DEV)
+    x1 = seeded_randn(55 + c, b, side * side, c).to(DEV)
+    wout, bout = (seeded_randn(56, c, c) / c ** 0.5).to(DEV), seeded_randn(57, c).to(DEV)
+    ref = ops.deform_combine(x1, ops.linear(o, wout, bout), b, side, side, c)
+    got = ops.deform_out_combine(o, wout, bout, x1, b, side, side, c)
+    assert rel_err(got.cpu(), ref.cpu()) < 2e-5
+
+
+def test_decoder_wiring_kernels():
+    """The data-movement kernels that replaced the decoder's / encoder tail's ATen launches (round 3), each against the torch
+    expression of the reference it stands for: AvgPool2d(2) (+ zero channel padding, NCHW or NHWC input; decoder.py:149-178),
+    channel-slice copies into a concatenated map (decoder.py:197,210,213) incl. the strided 3-of-T token slice (mTVE:745),
+    the view merge in front of the global embedding (mTVE:710-718,739) and PixelShuffle(2)(g*f) + gcn*freq (decoder.py:198-205).
+    The copies are bit-identical to torch's; the pooling / product kernels agree to fp32 rounding."""
+    x9 = seeded_randn(31, 2, 9, 224, 224)
+    ref = F.avg_pool2d(x9, 2)
+    y = ops.avgpool2_pad(x9.to(DEV), 32, nchw_in=True)
+    assert y.shape == (2, 32, 112, 112) and y.stride(1) == 1
+    assert rel_err(y[:, :9].cpu(), ref) < 1e-6 and not y[:, 9:].any()          # (summation order of the 2x2 window differs from ATen's)
+    x128 = seeded_randn(32, 2, 128, 28, 28)
+    y = ops.avgpool2_pad(x128.to(DEV).contiguous(memory_format=torch.channels_last))
+    assert rel_err(y.cpu(), F.avg_pool2d(x128, 2)) < 1e-6
+    # channel slices
+    a, bq = seeded_randn(33, 2, 256, 14, 14), seeded_randn(34, 2, 64, 14, 14)
+    cat = ops.empty_nhwc(2, 320, 14, 14, DEV)
+    ops.set_channels(cat, 0, a.to(DEV).contiguous(memory_format=torch.channels_last))
+    ops.set_channels(cat, 256, bq.to(DEV))                                   # NCHW-contiguous source: normalised to NHWC first
+    assert torch.equal(cat.cpu(), torch.cat([a, bq], 1))
+    g = seeded_randn(35, 3 * 49, 5 * 768).to(DEV)                             # global tokens (B*49, T*768), T = 5
+    view = g.reshape(3, 49, 5 * 768)[:, :, :2304].reshape(3, 7, 7, 2304).permute(0, 3, 1, 2)     # no copy: pitched pixels
+    assert view.data_ptr() == g.data_ptr()
+    cat1 = ops.empty_nhwc(3, 256 + 2304, 7, 7, DEV)
+    cat1.zero_()
+    ops.set_channels(cat1, 256, view)
+    assert torch.equal(cat1[:, 256:].cpu(), g.cpu().reshape(3, 49, 5, 768)[:, :, :3].reshape(3, 7, 7, 2304).permute(0, 3, 1, 2))
+    assert not cat1[:, :256].any()
+    # view merge
+    tt = [1, 1, 5]
+    views = [seeded_randn(36, 2, 49, 768), seeded_randn(37, 2, 49, 768), seeded_randn(38, 2, 5 * 49, 1024)]
+    parts = []
+    for v, t in zip(views, tt):
+        b, l, c = v.shape
+        v = v.reshape(b, t, l // t, c)
+        parts.append(v.repeat(1, 5 // t, 1, 1))
+    ref = torch.cat(parts, -1).permute(0, 2, 1, 3).reshape(2 * 49 * 5, 2560)   # mTVE:717-718, 739: (b t n c) -> (b n) t c
+    assert torch.equal(ops.merge_views([v.to(DEV) for v in views], tt).cpu(), ref)
+    # trunk head
+    gg, ff = seeded_randn(39, 2, 128, 7, 7), seeded_randn(40, 2, 128, 7, 7)
+    gcn, fr = seeded_randn(41, 2, 32, 14, 14), seeded_randn(42, 2, 32, 14, 14)
+    ref = gcn * fr + F.pixel_shuffle(gg * ff, 2)
+    assert rel_err(ops.trunk_head(gg.to(DEV), ff.to(DEV), gcn.to(DEV), fr.to(DEV)).cpu(), ref) < 1e-6
+
+
 @pytest.mark.parametrize("cin,cout,kh,kw,h", [(128, 128, 3, 3, 28), (256, 32, 7, 1, 14), (32, 32, 1, 7, 14), (768, 256, 3, 3, 28),
                                              (2816, 128, 7, 1, 7), (128, 128, 3, 3, 112), (32, 128, 3, 3, 7)])
 def test_conv2d_nhwc(cin, cout, kh, kw, h):
