@@ -1,0 +1,561 @@
+// backward.hip — backward kernels of the Swin block's non-attention parts (SURVEY 8f-2, rows 6-7 of 8a in training):
+// LayerNorm backward, exact-erf GELU forward/backward, 2-D transpose (operand layout for the weight-gradient GEMMs) and
+// deterministic column sums (bias gradients).  All HBM-bound streaming kernels; every reduction runs in a fixed order
+// (no atomics), so gradients are bitwise reproducible.
+//
+// Linear backward itself reuses mumpy_linear_fwd (y = x W^T):  dX = dY W  = linear(dY, W^T),  dW = dY^T X = linear(dY^T, X^T),
+// with the transposes produced by mumpy_transpose_fwd (mumpy_hip/autograd.py).
+#include "common.h"
+using namespace mumpy;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------
+// LayerNorm backward (nn.LayerNorm over the last dim, eps inside the sqrt; swin:266,305).  One wave per row:
+//   xhat = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
+// dgamma / dbeta: each block accumulates its rows in registers (lane owns columns lane, lane+64, ...) and writes one
+// partial row per wave; ln_bwd_reduce_kernel sums the partials in order.
+constexpr int LN_MAXC4 = 8;             // float4 columns per lane: C <= 64 * 4 * 8 = 2048 (PatchMerging's LayerNorm(4C) at C = 512)
+
+// NC4 = float4 columns per lane (C <= 256 * NC4), RU = rows in flight per wave: narrow rows are latency-bound (three
+// dependent wave reductions per row), so several independent rows are interleaved
+template <int NC4, int RU>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ dy, const float* __restrict__ dx_add,
+                                                     float* __restrict__ dx, float* __restrict__ partial, int64_t rows, int C,
+                                                     float eps, int rows_per_wave) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + wave;
+    const int n4 = C >> 2;                                  // float4 columns
+    const float invc = 1.0f / (float)C;
+    f32x4 dg[NC4], db[NC4], gm[NC4];
+#pragma unroll
+    for (int i = 0; i < NC4; ++i) {
+        dg[i] = f32x4{0, 0, 0, 0}; db[i] = f32x4{0, 0, 0, 0};
+        const int c4 = lane + 64 * i;
+        gm[i] = c4 < n4 ? reinterpret_cast<const f32x4*>(gamma)[c4] : f32x4{0, 0, 0, 0};
+    }
+    const int64_t r0 = gw * rows_per_wave;
+    const int64_t r1 = (r0 + rows_per_wave < rows) ? r0 + rows_per_wave : rows;
+    for (int64_t rb = r0; rb < r1; rb += RU) {
+        f32x4 xv[RU][NC4], dv[RU][NC4];
+        float s[RU], q[RU], sg[RU], sgx[RU];
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const int64_t r = (rb + u < r1) ? rb + u : r1 - 1;                 // tail rows recompute the last row (not stored)
+            s[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    xv[u][i] = reinterpret_cast<const f32x4*>(x + r * C)[c4];
+                    dv[u][i] = reinterpret_cast<const f32x4*>(dy + r * C)[c4];
+                    s[u] += (xv[u][i].x + xv[u][i].y) + (xv[u][i].z + xv[u][i].w);
+                } else { xv[u][i] = f32x4{0, 0, 0, 0}; dv[u][i] = f32x4{0, 0, 0, 0}; }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) s[u] += __shfl_xor(s[u], o);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float mean = s[u] * invc;
+            q[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    xv[u][i] -= mean;
+                    q[u] += (xv[u][i].x * xv[u][i].x + xv[u][i].y * xv[u][i].y) + (xv[u][i].z * xv[u][i].z + xv[u][i].w * xv[u][i].w);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) q[u] += __shfl_xor(q[u], o);
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            const float rstd = rsqrtf(q[u] * invc + eps);
+            const bool live = rb + u < r1;
+            q[u] = rstd;
+            sg[u] = 0.f; sgx[u] = 0.f;
+#pragma unroll
+            for (int i = 0; i < NC4; ++i) {
+                xv[u][i] *= rstd;                                              // xhat
+                if (live) { db[i] += dv[u][i]; dg[i] += dv[u][i] * xv[u][i]; }
+                dv[u][i] *= gm[i];                                             // g = dy * gamma
+                sg[u] += (dv[u][i].x + dv[u][i].y) + (dv[u][i].z + dv[u][i].w);
+                sgx[u] += (dv[u][i].x * xv[u][i].x + dv[u][i].y * xv[u][i].y) + (dv[u][i].z * xv[u][i].z + dv[u][i].w * xv[u][i].w);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1)
+#pragma unroll
+            for (int u = 0; u < RU; ++u) { sg[u] += __shfl_xor(sg[u], o); sgx[u] += __shfl_xor(sgx[u], o); }
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (rb + u >= r1) continue;
+            const float mg = sg[u] * invc, mgx = sgx[u] * invc, rstd = q[u];
+            f32x4* dxr = reinterpret_cast<f32x4*>(dx + (rb + u) * C);
+            const f32x4* dar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + (rb + u) * C) : nullptr;    // gradient of the
+#pragma unroll                                                                                              // residual branch
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    f32x4 g = (dv[u][i] - mg - xv[u][i] * mgx) * rstd;
+                    if (dar) g += dar[c4];
+                    dxr[c4] = g;
+                }
+            }
+        }
+    }
+    f32x4* pg = reinterpret_cast<f32x4*>(partial + gw * 2 * C);
+    f32x4* pb = reinterpret_cast<f32x4*>(partial + gw * 2 * C + C);
+#pragma unroll
+    for (int i = 0; i < NC4; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < n4) { pg[c4] = dg[i]; pb[c4] = db[i]; }
+    }
+}
+
+// out[c] = sum_p partial[p * stride + c]: 64 columns per block, 16 lane groups each summing every 16th partial, combined
+// through LDS in group order -- a fixed summation tree (bitwise reproducible) without a thousands-long serial chain
+__global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                              int64_t nparts, int64_t width, int64_t stride) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (i < width)
+        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * stride + i];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < width) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        out[i] = t;
+    }
+}
+
+// LayerNorm backward: partial rows [dgamma(C) | dbeta(C)] per wave -> dgamma, dbeta (the same fixed tree as
+// partial_reduce_kernel), written or ACCUMULATED in place (the caller's gradient buffer: no copies, no add kernels)
+__global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int64_t nparts, int C, int accum) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (i < 2 * C)
+        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * 2 * C + i];
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < 2 * C) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        float* o = i < C ? dgamma + i : dbeta + (i - C);
+        *o = accum ? *o + t : t;
+    }
+}
+
+// column sums of a (R, C) matrix: stage 1 writes one partial row per block of rows.  A block is 64 columns x 4 row lanes
+// (coalesced 256-B row segments, 4 rows in flight per column); the 4 row lanes are combined in order through LDS.
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t R,
+                                                              int C, int rows_per_block) {
+    __shared__ float red[4][64];
+    const int col = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int c = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (c < C)
+        for (int64_t r = r0 + rl; r < r0 + rows_per_block && r < R; r += 4) s += x[r * C + c];
+    red[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) partial[(int64_t)blockIdx.y * C + c] = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+}
+
+__device__ __forceinline__ float gelu_grad(float x) {          // d/dx [0.5 x (1 + erf(x / sqrt 2))]
+    const float cdf = 0.5f * (1.0f + erf_fast(x * 0.70710678118654752440f));
+    const float pdf = 0.3989422804014327f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const f32x4* __restrict__ x, f32x4* __restrict__ y, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x[i];
+        y[i] = f32x4{gelu_erf(v.x), gelu_erf(v.y), gelu_erf(v.z), gelu_erf(v.w)};
+    }
+}
+
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const f32x4* __restrict__ x, const f32x4* __restrict__ dy,
+                                                       f32x4* __restrict__ dx, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f32x4 v = x[i], d = dy[i];
+        dx[i] = f32x4{d.x * gelu_grad(v.x), d.y * gelu_grad(v.y), d.z * gelu_grad(v.z), d.w * gelu_grad(v.w)};
+    }
+}
+
+// out[b][i] = x[b][i] * scale[b]: stochastic depth (timm DropPath: per-sample Bernoulli mask / keep_prob); its own backward
+__global__ __launch_bounds__(256) void scale_samples_kernel(const f32x4* __restrict__ x, const float* __restrict__ scale,
+                                                            f32x4* __restrict__ out, int64_t per4) {
+    const float sc = scale[blockIdx.y];
+    const f32x4* xb = x + (int64_t)blockIdx.y * per4;
+    f32x4* ob = out + (int64_t)blockIdx.y * per4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per4; i += (int64_t)gridDim.x * 256) ob[i] = xb[i] * sc;
+}
+
+// out (C, R) = in (R, C)^T, 64x64 tiles through LDS (stride 65: conflict-free both ways)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t R, int64_t C) {
+    __shared__ float tile[64][65];
+    const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t r = r0 + ty + 4 * i, c = c0 + tx;
+        if (r < R && c < C) tile[ty + 4 * i][tx] = in[r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t c = c0 + ty + 4 * i, r = r0 + tx;
+        if (c < C && r < R) out[c * R + r] = tile[tx][ty + 4 * i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// GroupNorm (+ReLU) backward on NHWC (BaselineDecoder blocks, decoder.py:233-271).  With xhat = (z - mean_g) rstd_g,
+// pre = xhat gamma_c + beta_c, g = dy * [pre > 0] (ReLU) :
+//   dgamma_c = sum g xhat,  dbeta_c = sum g,  dz = rstd_g (g gamma_c - S1_g / n - xhat S2_g / n)
+//   S1_g = sum_{c in g} gamma_c T1[c],  S2_g = sum_{c in g} gamma_c T2[c],  T1[c] = sum_pixels g,  T2[c] = sum_pixels g xhat
+// pass 1 (grid (nsplit, B)): per-channel T1, T2 of its pixel range -> part[b][split][{T1,T2}][C]; pass 2: dz.
+// mean / rstd come from the forward's gn_stats partial sums (same layout, same fixed-order sum as the forward apply).
+__device__ __forceinline__ void gn_group_stats(const float* __restrict__ stats, int nsplit_s, int G, int b, int g, double n,
+                                               float eps, float& mean, float& rstd) {
+    double s = 0.0, q = 0.0;                                  // as in gn_apply_resample_kernel (decoder.hip): double, same order
+    for (int sp = 0; sp < nsplit_s; ++sp) {
+        const float* o = stats + (((int64_t)b * nsplit_s + sp) * G + g) * 2;
+        s += (double)o[0]; q += (double)o[1];
+    }
+    const double m = s / n;
+    double var = q / n - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                             const float* __restrict__ stats, int nsplit_s,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ part, int64_t HW, int C, int G, int nsplit,
+                                                             float eps, int relu) {
+    __shared__ float red[256][8];
+    __shared__ float gm[32], gr[32];
+    const int split = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int lpp = C >> 2, ppi = 256 / lpp, c4 = tid % lpp, pl = tid / lpp;
+    const int cg = C / G;
+    if (tid < G) gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
+    __syncthreads();
+    const int64_t per = (HW + nsplit - 1) / nsplit;
+    const int64_t p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
+    f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
+    if (pl < ppi) {
+        const int g = (4 * c4) / cg;
+        const float mean = gm[g], rstd = gr[g];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        const float* zb = z + (int64_t)b * HW * C + 4 * c4;
+        const float* db = dy + (int64_t)b * HW * C + 4 * c4;
+        for (int64_t p = p0 + pl; p < p1; p += ppi) {
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(zb + p * C) - mean) * rstd;
+            f32x4 d = *reinterpret_cast<const f32x4*>(db + p * C);
+            if (relu) {                                       // act: 1 = ReLU mask, 2 = sigmoid'(pre) = s (1 - s)
+                const f32x4 pre = xh * ga + be;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (relu == 1) { if (!(pre[e] > 0.f)) d[e] = 0.f; }
+                    else { const float sg = 1.0f / (1.0f + __expf(-pre[e])); d[e] *= sg * (1.0f - sg); }
+                }
+            }
+            t1 += d;
+            t2 += d * xh;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[tid][e] = t1[e]; red[tid][4 + e] = t2[e]; }
+    __syncthreads();
+    if (tid < lpp) {                                          // fixed order over the pixel slots
+        f32x4 a1 = {0, 0, 0, 0}, a2 = {0, 0, 0, 0};
+        for (int slot = 0; slot < ppi; ++slot)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a1[e] += red[slot * lpp + tid][e]; a2[e] += red[slot * lpp + tid][4 + e]; }
+        float* o = part + ((int64_t)b * nsplit + split) * 2 * C;
+        *reinterpret_cast<f32x4*>(o + 4 * tid) = a1;
+        *reinterpret_cast<f32x4*>(o + C + 4 * tid) = a2;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ z, const float* __restrict__ dy,
+                                                           const float* __restrict__ stats, int nsplit_s,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ part, float* __restrict__ dz, int64_t HW, int C,
+                                                           int G, int nsplit, float eps, int relu) {
+    __shared__ float gm[32], gr[32], s1[32], s2[32];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const int cg = C / G;
+    if (tid < G) {
+        gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int sp = 0; sp < nsplit; ++sp) {
+                const float* o = part + ((int64_t)b * nsplit + sp) * 2 * C;
+                t1 += o[c]; t2 += o[C + c];
+            }
+            a1 += gamma[c] * t1; a2 += gamma[c] * t2;
+        }
+        const float n = (float)HW * (float)cg;
+        s1[tid] = a1 / n; s2[tid] = a2 / n;
+    }
+    __syncthreads();
+    const int lpp = C >> 2;
+    const int64_t total = HW * lpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % lpp);
+        const int64_t p = i / lpp;
+        const int g = (4 * c4) / cg;
+        const float mean = gm[g], rstd = gr[g];
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), be = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        const int64_t off = ((int64_t)b * HW + p) * C + 4 * c4;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(z + off) - mean) * rstd;
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + off);
+        if (relu) {
+            const f32x4 pre = xh * ga + be;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (relu == 1) { if (!(pre[e] > 0.f)) d[e] = 0.f; }
+                else { const float sg = 1.0f / (1.0f + __expf(-pre[e])); d[e] *= sg * (1.0f - sg); }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dz + off) = (d * ga - s1[g] - xh * s2[g]) * rstd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward of the bilinear x2 / x4 upsample (nn.Upsample(scale_factor=s, mode="bilinear"), NHWC): every input pixel gathers
+// from the output pixels that read it in the forward, with the forward's own index/weight function (deterministic).
+__device__ __forceinline__ void up_src(int o, int in, int out, int scale, int align, int& i0, int& i1, float& l0, float& l1) {
+    float src;
+    if (align) src = (out > 1) ? ((float)(in - 1) / (float)(out - 1)) * (float)o : 0.f;
+    else { src = (1.0f / (float)scale) * ((float)o + 0.5f) - 0.5f; if (src < 0.f) src = 0.f; }
+    i0 = (int)src;
+    i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+    l1 = src - (float)i0;
+    l0 = 1.f - l1;
+}
+
+__global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int H, int W, int C,
+                                                           int scale, int align) {
+    const int b = blockIdx.y;
+    const int lpp = C >> 2;
+    const int Ho = scale * H, Wo = scale * W;
+    const int64_t total = (int64_t)H * W * lpp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(i % lpp);
+        const int64_t p = i / lpp;
+        const int x = (int)(p % W), y = (int)(p / W);
+        f32x4 acc = {0, 0, 0, 0};
+        // candidate outputs: source coordinate within (y-1, y+1) -> o in [scale*(y-1) - scale, scale*(y+1) + scale]
+        for (int oy = scale * (y - 2); oy <= scale * (y + 2); ++oy) {
+            if (oy < 0 || oy >= Ho) continue;
+            int y0, y1; float ly0, ly1;
+            up_src(oy, H, Ho, scale, align, y0, y1, ly0, ly1);
+            const float wy = (y0 == y ? ly0 : 0.f) + (y1 == y ? ly1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = scale * (x - 2); ox <= scale * (x + 2); ++ox) {
+                if (ox < 0 || ox >= Wo) continue;
+                int x0, x1; float lx0, lx1;
+                up_src(ox, W, Wo, scale, align, x0, x1, lx0, lx1);
+                const float wx = (x0 == x ? lx0 : 0.f) + (x1 == x ? lx1 : 0.f);
+                if (wx == 0.f) continue;
+                acc += *reinterpret_cast<const f32x4*>(dy + (((int64_t)b * Ho + oy) * Wo + ox) * C + 4 * c4) * (wy * wx);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + (((int64_t)b * H + y) * W + x) * C + 4 * c4) = acc;
+    }
+}
+
+}  // namespace
+
+static int64_t ln_bwd_waves(int64_t rows) {            // waves (= partial rows): enough to fill the chip, >= 8 rows each
+    int64_t w = (rows + 7) / 8;
+    if (w > 2048) w = 2048;
+    if (w < 4) w = 4;
+    return (w + 3) / 4 * 4;
+}
+
+extern "C" int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return (ln_bwd_waves(rows) + 1) * 2 * C * (int64_t)sizeof(float);      // partial rows + one reduced [dgamma | dbeta] row
+}
+
+extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dx_add, float* dx,
+                                   float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes, int64_t rows, int C,
+                                   float eps, int accumulate, void* stream) {
+    if (rows == 0) return 0;
+    MUMPY_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && workspace, MUMPY_ENULL, "layernorm_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(gamma) && aligned16(dy) && aligned16(dx) && aligned16(dx_add) && aligned16(workspace),
+                  MUMPY_EALIGN, "layernorm_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "layernorm_bwd: accumulate must be 0 or 1");
+    MUMPY_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXC4, MUMPY_EINVAL, "layernorm_bwd: unsupported C=%d", C);
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_layernorm_bwd_workspace_bytes(rows, C), MUMPY_EINVAL, "layernorm_bwd: workspace too small");
+    const int64_t waves = ln_bwd_waves(rows);
+    const int rpw = (int)((rows + waves - 1) / waves);
+    float* partial = static_cast<float*>(workspace);
+#define MUMPY_LN_BWD(NC4_, RU_)                                                                                     \
+    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx_add, dx, \
+                       partial, rows, C, eps, rpw)
+    if (C <= 256) MUMPY_LN_BWD(1, 4);
+    else if (C <= 512) MUMPY_LN_BWD(2, 2);
+    else if (C <= 1024) MUMPY_LN_BWD(4, 1);
+    else MUMPY_LN_BWD(8, 1);
+#undef MUMPY_LN_BWD
+    MUMPY_CHECK_LAUNCH("layernorm_bwd");
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, dgamma,
+                       dbeta, waves, C, accumulate);
+    MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce)");
+    return 0;
+}
+
+extern "C" int mumpy_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (n == 0) return 0;
+    MUMPY_REQUIRE(x && y, MUMPY_ENULL, "gelu: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(y) && n % 4 == 0, MUMPY_EALIGN, "gelu: need 16-byte aligned buffers and n %% 4 == 0");
+    int64_t grid = (n / 4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<f32x4*>(y), n / 4);
+    MUMPY_CHECK_LAUNCH("gelu_fwd");
+    return 0;
+}
+
+extern "C" int mumpy_gelu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+    if (n == 0) return 0;
+    MUMPY_REQUIRE(x && dy && dx, MUMPY_ENULL, "gelu_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(dy) && aligned16(dx) && n % 4 == 0, MUMPY_EALIGN,
+                  "gelu_bwd: need 16-byte aligned buffers and n %% 4 == 0");
+    int64_t grid = (n / 4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), reinterpret_cast<const f32x4*>(x),
+                       reinterpret_cast<const f32x4*>(dy), reinterpret_cast<f32x4*>(dx), n / 4);
+    MUMPY_CHECK_LAUNCH("gelu_bwd");
+    return 0;
+}
+
+extern "C" int mumpy_transpose_fwd(const float* in, float* out, int64_t R, int64_t C, void* stream) {
+    if (R == 0 || C == 0) return 0;
+    MUMPY_REQUIRE(in && out, MUMPY_ENULL, "transpose: null pointer");
+    MUMPY_REQUIRE(R > 0 && C > 0 && (R + 63) / 64 < 65536, MUMPY_EINVAL, "transpose: bad shape");
+    hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, as_stream(stream),
+                       in, out, R, C);
+    MUMPY_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+static int64_t col_sum_blocks(int64_t R) {             // row blocks: >= 64 rows each, enough of them to fill the chip
+    int64_t b = (R + 63) / 64;
+    if (b > 2048) b = 2048;
+    return b < 1 ? 1 : b;
+}
+
+extern "C" int64_t mumpy_col_sum_workspace_bytes(int64_t R, int C) {
+    if (R <= 0 || C <= 0) return 0;
+    return col_sum_blocks(R) * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, int64_t workspace_bytes, int64_t R, int C,
+                                 void* stream) {
+    MUMPY_REQUIRE(x && out && workspace, MUMPY_ENULL, "col_sum: null pointer");
+    MUMPY_REQUIRE(R > 0 && C > 0, MUMPY_EINVAL, "col_sum: bad shape");
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_col_sum_workspace_bytes(R, C), MUMPY_EINVAL, "col_sum: workspace too small");
+    const int64_t nb = col_sum_blocks(R);
+    const int rpb = (int)((R + nb - 1) / nb);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)nb), dim3(256), 0, as_stream(stream), x,
+                       partial, R, C, rpb);
+    MUMPY_CHECK_LAUNCH("col_sum(partial)");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, out, nb,
+                       (int64_t)C, (int64_t)C);
+    MUMPY_CHECK_LAUNCH("col_sum(reduce)");
+    return 0;
+}
+
+static int gn_bwd_splits(int64_t HW, int C) {
+    int64_t s = (HW * C) / 65536;
+    if (s > 64) s = 64;
+    return s < 1 ? 1 : (int)s;
+}
+
+extern "C" int64_t mumpy_gn_bwd_workspace_bytes(int B, int64_t HW, int C) {
+    if (B <= 0 || HW <= 0 || C <= 0) return 0;
+    return (int64_t)B * gn_bwd_splits(HW, C) * 2 * C * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_stats, const float* gamma,
+                                 const float* beta, const float* dy, float* dz, float* dgamma, float* dbeta, void* workspace,
+                                 int64_t workspace_bytes, int B, int64_t HW, int C, int G, float eps, int relu, void* stream) {
+    MUMPY_REQUIRE(z && stats_partial && gamma && beta && dy && dz && dgamma && dbeta && workspace, MUMPY_ENULL, "gn_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(z) && aligned16(dy) && aligned16(dz) && aligned16(gamma) && aligned16(beta) && aligned16(workspace),
+                  MUMPY_EALIGN, "gn_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && HW > 0 && nsplit_stats > 0, MUMPY_EINVAL, "gn_bwd: bad sizes");
+    MUMPY_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && G > 0 && G <= 32 && C % G == 0 && (C / G) % 4 == 0, MUMPY_EINVAL,
+                  "gn_bwd: unsupported C=%d G=%d", C, G);
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_gn_bwd_workspace_bytes(B, HW, C), MUMPY_EINVAL, "gn_bwd: workspace too small");
+    const int ns = gn_bwd_splits(HW, C);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(ns, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial, nsplit_stats, gamma,
+                       beta, part, HW, C, G, ns, eps, relu);
+    MUMPY_CHECK_LAUNCH("gn_bwd(partial)");
+    int64_t grid = (HW * (C / 4) + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial,
+                       nsplit_stats, gamma, beta, part, dz, HW, C, G, ns, eps, relu);
+    MUMPY_CHECK_LAUNCH("gn_bwd(apply)");
+    // dbeta[c] = sum over (b, split) of T1, dgamma[c] of T2: partial rows are [T1(C) | T2(C)]
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part, dbeta,
+                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
+    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dbeta)");
+    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part + C, dgamma,
+                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
+    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dgamma)");
+    return 0;
+}
+
+extern "C" int mumpy_upsample_bwd_nhwc(const float* dy, float* dx, int B, int H, int W, int C, int scale, int align_corners,
+                                       void* stream) {
+    MUMPY_REQUIRE(dy && dx, MUMPY_ENULL, "upsample_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(dy) && aligned16(dx), MUMPY_EALIGN, "upsample_bwd: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && H > 0 && W > 0 && C > 0 && C % 4 == 0 && (scale == 2 || scale == 4), MUMPY_EINVAL,
+                  "upsample_bwd: bad shape or scale %d", scale);
+    int64_t grid = ((int64_t)H * W * (C / 4) + 255) / 256;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(upsample_bwd_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), dy, dx, H, W, C, scale,
+                       align_corners);
+    MUMPY_CHECK_LAUNCH("upsample_bwd");
+    return 0;
+}
+
+extern "C" int mumpy_scale_samples_fwd(const float* x, const float* scale, float* out, int B, int64_t per_sample, void* stream) {
+    if (B == 0 || per_sample == 0) return 0;
+    MUMPY_REQUIRE(x && scale && out, MUMPY_ENULL, "scale_samples: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(out) && per_sample % 4 == 0, MUMPY_EALIGN,
+                  "scale_samples: need 16-byte aligned buffers and per_sample %% 4 == 0");
+    MUMPY_REQUIRE(B > 0 && B <= 65535 && per_sample > 0, MUMPY_EINVAL, "scale_samples: bad shape");
+    int64_t grid = (per_sample / 4 + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(scale_samples_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const f32x4*>(x), scale, reinterpret_cast<f32x4*>(out), per_sample / 4);
+    MUMPY_CHECK_LAUNCH("scale_samples");
+    return 0;
+}

@@ -1,0 +1,74 @@
+// common.h — shared helpers for the libmumpy_hip.so kernels (gfx950 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/mumpy_hip.h"
+
+namespace mumpy {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int WAVE = 64;
+constexpr int WS = 7;        // window side
+constexpr int WT = 49;       // tokens per window
+constexpr int HD = 32;       // head width of every Swin / deformable head
+
+void set_error(const char* fmt, ...);
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// Every launch goes through this: reports launch-time errors without synchronising.
+#define MUMPY_CHECK_LAUNCH(name)                                                     \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            mumpy::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));  \
+            return (int)e_;                                                          \
+        }                                                                            \
+    } while (0)
+
+#define MUMPY_REQUIRE(cond, code, ...)                                               \
+    do {                                                                             \
+        if (!(cond)) {                                                               \
+            mumpy::set_error(__VA_ARGS__);                                           \
+            return code;                                                             \
+        }                                                                            \
+    } while (0)
+
+__device__ __forceinline__ float wave_sum(float v, int width) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1)
+        if (o < width) v += __shfl_xor(v, o);
+    return v;
+}
+
+// erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 fma instead of
+// libm erff's ~40-instruction piecewise path -- the GELU epilogue of the fc1 GEMMs is VALU-bound otherwise.
+__device__ __forceinline__ float erf_fast(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float y = 1.0f - p * t * __expf(-ax * ax);
+    return copysignf(y, x);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_fast(x * 0.70710678118654752440f)); }
+
+// raster token of in-window position p of window (wy,wx) on a (Hs,W) grid after roll(-shift)
+// (swin:54-66 + 273): shifted[y][x] = src[(y+shift)%Hs][(x+shift)%W].
+__device__ __forceinline__ int window_token(int wy, int wx, int p, int Hs, int W, int shift) {
+    int py = p / WS, px = p - py * WS;
+    int y = wy * WS + py + shift;
+    int x = wx * WS + px + shift;
+    if (y >= Hs) y -= Hs;
+    if (x >= W) x -= W;
+    return y * W + x;
+}
+
+}  // namespace mumpy

@@ -1,0 +1,146 @@
+// temporal_attention.hip — attention of the 12 global ViT blocks (blocks:57-71).  Under vmap(in_dims=2) (mTVE:741)
+// every one of the B*49 spatial sites is its own sequence of T <= 16 temporal tokens, 12 heads of width 64: the
+// score matrix is T x T.  One wave per (site, head), lane = channel: q/k/v rows are 256-B coalesced loads, a score is
+// a 64-lane reduction, softmax and P V are per-lane scalar work.  Negligible FLOPs; the point is one launch and no
+// (S,heads,T,T) tensors in HBM.
+#include "common.h"
+using namespace mumpy;
+
+namespace {
+constexpr int TMAX = 16;
+
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                            int64_t units, int T, int C, int heads, float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= units) return;
+    const int head = (int)(u % heads);
+    const int64_t s = u / heads;
+    const float* base = qkv + s * T * 3 * C + head * 64 + lane;
+    float q[TMAX], k[TMAX], v[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (t < T) {
+            const float* r = base + (int64_t)t * 3 * C;
+            q[t] = r[0];
+            k[t] = r[C];
+            v[t] = r[2 * C];
+        }
+    }
+    float* ob = out + s * T * C + head * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) continue;
+        float sc[TMAX];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            if (j < T) {
+                sc[j] = wave_sum(q[t] * k[j], 64) * scale;     // scale on the product (blocks:66)
+                m = fmaxf(m, sc[j]);
+            }
+        }
+        float sum = 0.f, o = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            if (j < T) {
+                const float e = __expf(sc[j] - m);
+                sum += e;
+                o = fmaf(e, v[j], o);
+            }
+        }
+        ob[(int64_t)t * C] = o / sum;
+    }
+}
+
+// backward: per (site, head) the T x T probabilities are recomputed; with g = P o (dP - rowsum(P o dP)), dP = dO V^T:
+//   dQ = scale g K,  dK = scale g^T Q,  dV = P^T dO.   Same one-wave-per-unit layout (lane = channel).
+__global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, int64_t units, int T, int C, int heads,
+                                                                float scale) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= units) return;
+    const int head = (int)(u % heads);
+    const int64_t s = u / heads;
+    const float* base = qkv + s * T * 3 * C + head * 64 + lane;
+    const float* dob = dout + s * T * C + head * 64 + lane;
+    float q[TMAX], k[TMAX], v[TMAX], d_o[TMAX], dq[TMAX], dk[TMAX], dv[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        dq[t] = 0.f; dk[t] = 0.f; dv[t] = 0.f;
+        if (t < T) {
+            const float* r = base + (int64_t)t * 3 * C;
+            q[t] = r[0]; k[t] = r[C]; v[t] = r[2 * C];
+            d_o[t] = dob[(int64_t)t * C];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        if (t >= T) continue;
+        float p[TMAX], dp[TMAX];
+        float m = -3.0e38f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j)
+            if (j < T) {
+                p[j] = wave_sum(q[t] * k[j], 64) * scale;
+                dp[j] = wave_sum(d_o[t] * v[j], 64);
+                m = fmaxf(m, p[j]);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j)
+            if (j < T) { p[j] = __expf(p[j] - m); sum += p[j]; }
+        const float inv = 1.0f / sum;
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j)
+            if (j < T) { p[j] *= inv; dsum += p[j] * dp[j]; }
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j)
+            if (j < T) {
+                const float g = p[j] * (dp[j] - dsum) * scale;
+                dq[t] = fmaf(g, k[j], dq[t]);
+                dk[j] = fmaf(g, q[t], dk[j]);
+                dv[j] = fmaf(p[j], d_o[t], dv[j]);
+            }
+    }
+    float* ob = dqkv + s * T * 3 * C + head * 64 + lane;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t)
+        if (t < T) {
+            float* r = ob + (int64_t)t * 3 * C;
+            r[0] = dq[t]; r[C] = dk[t]; r[2 * C] = dv[t];
+        }
+}
+}  // namespace
+
+extern "C" int mumpy_temporal_attention_bwd(const float* qkv, const float* dout, float* dqkv, int64_t S, int T, int C, int heads,
+                                            float scale, void* stream) {
+    MUMPY_REQUIRE(qkv && dout && dqkv, MUMPY_ENULL, "temporal_attention_bwd: null pointer");
+    MUMPY_REQUIRE(S >= 0 && T >= 1 && T <= TMAX, MUMPY_ERANGE, "temporal_attention_bwd: T=%d outside 1..16", T);
+    MUMPY_REQUIRE(heads > 0 && C == heads * 64, MUMPY_EINVAL, "temporal_attention_bwd: need head width 64 (C=%d heads=%d)", C, heads);
+    if (S == 0) return 0;
+    const int64_t units = S * heads;
+    const int64_t grid = (units + 3) / 4;
+    MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "temporal_attention_bwd: too many sites");
+    hipLaunchKernelGGL(temporal_attn_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), qkv, dout, dqkv, units, T, C,
+                       heads, scale);
+    MUMPY_CHECK_LAUNCH("temporal_attention_bwd");
+    return 0;
+}
+
+extern "C" int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T, int C, int heads,
+                                            float scale, void* stream) {
+    MUMPY_REQUIRE(qkv && out, MUMPY_ENULL, "temporal_attention: null pointer");
+    MUMPY_REQUIRE(S >= 0 && T >= 1 && T <= TMAX, MUMPY_ERANGE, "temporal_attention: T=%d outside 1..16", T);
+    MUMPY_REQUIRE(heads > 0 && C == heads * 64, MUMPY_EINVAL, "temporal_attention: need head width 64 (C=%d heads=%d)", C, heads);
+    if (S == 0) return 0;
+    const int64_t units = S * heads;
+    const int64_t grid = (units + 3) / 4;
+    MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "temporal_attention: too many sites");
+    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), qkv, out, units, T, C,
+                       heads, scale);
+    MUMPY_CHECK_LAUNCH("temporal_attention");
+    return 0;
+}

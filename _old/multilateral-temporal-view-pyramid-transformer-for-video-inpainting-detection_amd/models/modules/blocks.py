@@ -1,0 +1,77 @@
+"""Global temporal ViT blocks (reference models/modules/blocks.py) on the HIP kernels.
+
+The encoder applies these with the 49 spatial sites as the vmapped axis (mTVE:741), i.e. every site is an independent
+sequence of T temporal tokens.  Here that is simply a (B*49, T, 768) batch: LN -> QKV GEMM -> one T x T attention
+launch for all sites and heads -> proj GEMM(+residual) -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+residual).
+"""
+import torch.nn as nn
+
+from models.modules.layers import DropPath
+from mumpy_hip import ops
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, hidden_dim, dropout, out_dim=None):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden_dim)
+        self.act = nn.GELU()
+        self.fc2 = nn.Linear(hidden_dim, dim if out_dim is None else out_dim)
+        self.drop = nn.Dropout(dropout)
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def forward(self, x, residual=None):
+        h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
+
+    def forward_bf16(self, x16, residual):
+        """bf16 storage: bf16 LayerNorm output in, bf16 hidden tensor, fc2 adds into the fp32 residual stream."""
+        from models.modules.swinTransformer import _w16
+        h = ops.linear_bf16s(x16, _w16(self, "fc1"), self.fc1.bias, act=ops.ACT_GELU, out_bf16=True)
+        return ops.linear_bf16s(h, _w16(self, "fc2"), self.fc2.bias, residual=residual, out_bf16=False)
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, heads, dropout):
+        super().__init__()
+        self.heads = heads
+        self.scale = (dim // heads) ** -0.5
+        if dim // heads != 64:
+            raise NotImplementedError("HIP temporal attention is built for 64-wide heads")
+        self.attn = None
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.attn_drop = nn.Dropout(dropout)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(dropout)
+
+    @property
+    def unwrapped(self):
+        return self
+
+    def forward(self, x, mask=None, residual=None):
+        """x (S,T,C) -> (attention output after proj (+residual), None); the TxT map is not materialised."""
+        s, t, c = x.shape
+        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
+        a = ops.temporal_attention(qkv, s, t, c, self.heads, self.scale)
+        return ops.linear(a, self.proj.weight, self.proj.bias, residual=residual), None
+
+
+class Block(nn.Module):
+    def __init__(self, dim, heads, mlp_dim, dropout, drop_path):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn = Attention(dim, heads, dropout)
+        self.mlp = FeedForward(dim, mlp_dim, dropout)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+
+    def forward(self, x, mask=None, return_attention=False):
+        if return_attention:
+            raise NotImplementedError("attention maps are not materialised")
+        self.drop_path(x)
+        x, _ = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), mask, residual=x)
+        if ops.storage() == "bf16" and isinstance(self.mlp, FeedForward):
+            return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
+        return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x)

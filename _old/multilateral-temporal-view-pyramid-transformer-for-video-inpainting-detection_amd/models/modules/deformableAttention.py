@@ -1,0 +1,100 @@
+"""Window-based deformable cross-view attention (SwinDAttention) on the MI355X HIP kernels.
+
+State_dict keys and constructor follow the reference's models/modules/deformableAttention.py:218-309.  Execution is
+six launches on raster-ordered tokens:  proj_q GEMM -> offsets kernel (depthwise 5x5 + LN + GELU + 1x1 + tanh) ->
+bilinear sampling kernel -> [proj_k|proj_v] as ONE GEMM with concatenated weights -> fused attention + r-tuple
+aggregation kernel -> proj_out GEMM.  The reference's index behaviour is specification and is reproduced exactly:
+kv window i pairs with q window (i mod B1) (`x1.repeat`, deform:330), the "(b t)" sum adds ADJACENT kv windows
+(deform:394-395), and the output is the flat (C,49) image re-read as (49,C) (deform:403).  The (B, r*nH, 49, 49)
+attention tensor the reference also returns is discarded by its only caller (mTVE:284) and is not materialised.
+"""
+import torch
+import torch.nn as nn
+
+from models.modules.layers import Derived
+from mumpy_hip import ops
+
+
+class LayerNormProxy(nn.Module):
+    """LayerNorm over channels of a (B,C,H,W) map; inside the HIP offsets kernel this is fused, the module only
+    holds the parameters (key `...conv_offset.1.norm.*`)."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+
+    def forward(self, x):                       # (B,C,H,W), API parity only
+        b, c, h, w = x.shape
+        y = ops.layernorm(x.permute(0, 2, 3, 1).contiguous(), self.norm.weight, self.norm.bias, self.norm.eps)
+        return y.permute(0, 3, 1, 2)
+
+
+class SwinDAttention(nn.Module):
+    def __init__(self, dim1, n_heads, attn_drop, n_groups, ws=7, stride=1, offset_range_factor=2, no_off=False,
+                 height_scale=[1, 1], dwc_pe=False, use_pe=False, fixed_pe=False):
+        super().__init__()
+        if ws != 7 or stride != 1 or offset_range_factor != 2 or no_off or use_pe or dwc_pe or fixed_pe or n_groups != 3:
+            raise NotImplementedError("only the configuration the encoder instantiates (mTVE:131) is built: "
+                                      "ws=7, n_groups=3, offset_range_factor=2, no positional-encoding branches")
+        self.n_heads, self.ws, self.n_groups = n_heads, ws, n_groups
+        self.n_head_channels = dim1 // n_heads
+        if self.n_head_channels != 32:
+            raise NotImplementedError("HIP deformable attention is built for 32-wide heads")
+        self.scale = self.n_head_channels ** -0.5
+        self.nc = dim1
+        self.n_group_channels = cg = dim1 // n_groups
+        self.conv_offset = nn.Sequential(
+            nn.Conv2d(cg, cg, 5, 1, 2, groups=cg),
+            LayerNormProxy(cg),
+            nn.GELU(),
+            nn.Conv2d(cg, 2, 1, 1, 0, bias=False))
+        self.proj_q = nn.Conv2d(dim1, dim1, 1)
+        self.proj_k = nn.Conv2d(dim1, dim1, 1)
+        self.proj_v = nn.Conv2d(dim1, dim1, 1)
+        self.proj_out = nn.Conv2d(dim1, dim1, 1)
+        self.proj_drop = nn.Dropout(attn_drop)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.rpe_table = None
+        for m in (self.proj_q, self.proj_k, self.proj_v):       # deform:302-309
+            nn.init.trunc_normal_(m.weight)
+            nn.init.zeros_(m.bias)
+        nn.init.zeros_(self.proj_out.weight)
+        nn.init.zeros_(self.proj_out.bias)
+        self._wkv, self._bkv, self._pad = Derived(), Derived(), Derived()
+
+    def _run(self, x1, x2, q_grid, kv_grid):
+        """q_grid = (b, h, w): x1 is (b, h*w, C) raster;  kv_grid = (b2, hs2, w2): x2 is (b2, hs2*w2, C) raster.
+        Returns proj_out output Yt (nq, 49, C): window-major, token-major, i.e. BEFORE the deform:403 reshape."""
+        c = self.nc
+        b, h, w = q_grid
+        b2, hs2, w2 = kv_grid
+        nq = b * (h // 7) * (w // 7)
+        nkv = b2 * (hs2 // 7) * (w2 // 7)
+        if nkv % nq:
+            raise RuntimeError(f"SwinDAttention: {nkv} kv windows is not a multiple of {nq} q windows")
+        q = ops.linear(x1, self.proj_q.weight, self.proj_q.bias)
+        off = self.conv_offset
+        pos = ops.deform_offsets(q, off[0].weight, off[0].bias, off[1].norm.weight, off[1].norm.bias, off[3].weight,
+                                 b, h, w, c)
+        sampled = ops.deform_sample(x2, pos, b2, hs2, w2, c, nq)
+        wkv = self._wkv.get((self.proj_k.weight, self.proj_v.weight),
+                            lambda: torch.cat([self.proj_k.weight.reshape(c, c), self.proj_v.weight.reshape(c, c)], 0))
+        bkv = self._bkv.get((self.proj_k.bias, self.proj_v.bias), lambda: torch.cat([self.proj_k.bias, self.proj_v.bias]))
+        kv = ops.linear(sampled, wkv, bkv)                                        # (nkv,49,2C)
+        pad = self._pad.get((self.proj_q.weight,), lambda: ops.pad_mask().to(x1.device))
+        o = ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)   # (nq,49,C)
+        return ops.linear(o, self.proj_out.weight, self.proj_out.bias)
+
+    def attend_raster(self, x1, x2, b, h, w, hs2):
+        """Fused-block entry: x1 (B, h*w, C) q-side tokens, x2 (B, hs2*w, C) kv-side tokens (already through
+        `pre`), both raster with frames stacked on rows."""
+        return self._run(x1, x2, (b, h, w), (b, hs2, w))
+
+    def forward(self, x1, x2, return_attention=False):
+        """Reference signature (deform:324): x1 (B1,49,C) q windows, x2 (B2,49,C) kv windows, B2 = r*B1.
+        Every window is its own 7x7 image for the kernels.  Returns (y (B1,49,C), None)."""
+        if return_attention:
+            raise NotImplementedError("the attention map is never materialised (its caller discards it, mTVE:284)")
+        b1, b2, c = x1.shape[0], x2.shape[0], x1.shape[2]
+        yt = self._run(x1, x2, (b1, 7, 7), (b2, 7, 7))
+        return yt.transpose(1, 2).reshape(b1, 49, c), None       # flat (C,49) re-read as (49,C) (deform:403)

@@ -1,0 +1,613 @@
+"""SURVEY 8f-2, first slice: backward of the Swin block (rows 5-7 of 8a) on HIP kernels.  Goldens (`blk_s0`, `blk_s3` in
+tests/golden/train_tail.npz) are the reference's own SwinTransformerBlock run forward + backward under torch autograd
+(tests/golden/gen_train_goldens.py).  CPU: the oracle under autograd reproduces them.  GPU: every backward kernel against
+torch autograd of the same op, and the whole block through mumpy_hip.autograd against the goldens."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN, rel_err
+from oracle import mumpy_oracle as O
+from weight_fill import fill_module_, seeded_randn
+
+TAGS = [("blk_s0", 0), ("blk_s3", 3)]
+GRAD_TOL = 2e-4            # fp32, sums over 392 tokens / 49 keys in a different order than torch's
+
+
+def _block(shift):
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = SwinTransformerBlock(dim=96, input_resolution=(14, 14), num_heads=3, window_size=7, shift_size=shift)
+    return fill_module_(blk).eval()
+
+
+@pytest.mark.parametrize("tag,shift", TAGS)
+def test_oracle_autograd_matches_reference_block(train_golden, tag, shift):
+    blk = _block(shift)
+    sd = {"b." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "attn_mask" not in k and "index" not in k)
+          for k, v in blk.state_dict().items()}
+    x = seeded_randn(700 + shift, 2, 196, 96).requires_grad_(True)
+    g = seeded_randn(710 + shift, 2, 196, 96)
+    y = O.swin_block(x, sd, "b", 14, 14, shift)
+    (y * g).sum().backward()
+    assert rel_err(y.detach(), train_golden[tag + "/y"]) < 2e-5
+    assert rel_err(x.grad, train_golden[tag + "/dx"]) < 5e-5
+    for name, _ in blk.named_parameters():
+        assert rel_err(sd["b." + name].grad, train_golden[f"{tag}/grad/{name}"]) < 5e-5, name
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("rows,c", [(392, 96), (37, 128), (1000, 768), (5, 1024)])
+def test_hip_layernorm_bwd(rows, c):
+    from mumpy_hip import ops
+    x = (seeded_randn(1, rows, c) * 2 + 0.5).requires_grad_(True)
+    gm, bt = (1 + 0.1 * seeded_randn(2, c)).requires_grad_(True), (0.1 * seeded_randn(3, c)).requires_grad_(True)
+    dy = seeded_randn(4, rows, c)
+    F.layer_norm(x, (c,), gm, bt, 1e-5).backward(dy)
+    dx, dg, db = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5)
+    assert rel_err(dx.cpu(), x.grad) < 2e-5 and rel_err(dg.cpu(), gm.grad) < 2e-5 and rel_err(db.cpu(), bt.grad) < 2e-5
+    dx2, dg2, db2 = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5)
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)          # fixed-order reductions
+    # residual-branch gradient folded into dx, parameter gradients accumulated in place (the flat gradient buffer's views)
+    extra = seeded_randn(6, rows, c)
+    gacc, bacc = torch.full((c,), 0.5, device="cuda"), torch.full((c,), -2.0, device="cuda")
+    dx3, r1, r2 = ops.layernorm_bwd(x.detach().cuda(), gm.detach().cuda(), dy.cuda(), 1e-5, dx_add=extra.cuda(), dg_out=gacc, db_out=bacc)
+    assert r1 is None and r2 is None
+    assert rel_err(dx3.cpu(), x.grad + extra) < 2e-5
+    assert rel_err(gacc.cpu() - 0.5, gm.grad) < 2e-5 and rel_err(bacc.cpu() + 2.0, bt.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(392, 768, 3072), (1568, 384, 1536), (50, 96, 96), (6272, 288, 96), (1000, 64, 32), (31360, 384, 128),
+                                   (7840, 2048, 512), (37, 32, 32), (1960, 2304, 768)])
+def test_hip_linear_bwd_one_call(m, n, k):
+    """mumpy_linear_bwd: dX = dY W, dW = dY^T X, db = colsum(dY) from the row-major tensors (no transposed copies; token
+    counts that are no multiple of 32 or of the tile), vs float64 products; accumulate mode adds into existing buffers;
+    split contractions reduce in a fixed order (bitwise reproducible)."""
+    from mumpy_hip import ops
+    x, w, dy = seeded_randn(1, m, k), seeded_randn(2, n, k) / k ** 0.5, seeded_randn(3, m, n)
+    xd, wd, dyd = x.cuda(), w.cuda(), dy.cuda()
+    dx, dw, db = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=True, need_db=True)
+    ref_dx, ref_dw, ref_db = dy.double() @ w.double(), dy.double().t() @ x.double(), dy.double().sum(0)
+    assert rel_err(dx.cpu(), ref_dx) < 1e-5 and rel_err(dw.cpu(), ref_dw) < 1e-5 and rel_err(db.cpu(), ref_db) < 1e-5
+    dx2, dw2, db2 = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=True, need_db=True)
+    assert torch.equal(dx, dx2) and torch.equal(dw, dw2) and torch.equal(db, db2)
+    gw, gb = seeded_randn(4, n, k).cuda(), seeded_randn(5, n).cuda()
+    gw0, gb0 = gw.clone(), gb.clone()
+    r = ops.linear_bwd(xd, wd, dyd, need_dx=False, need_dw=True, need_db=True, dw_out=gw, db_out=gb)
+    assert r == (None, None, None)
+    assert rel_err(gw.cpu(), gw0.cpu().double() + ref_dw) < 1e-5 and rel_err(gb.cpu(), gb0.cpu().double() + ref_db) < 1e-5
+    only_dx = ops.linear_bwd(xd, wd, dyd, need_dx=True, need_dw=False, need_db=False)
+    assert torch.equal(only_dx[0], dx) and only_dx[1] is None and only_dx[2] is None
+
+
+@pytest.mark.gpu
+def test_hip_linear_fn_accumulates_into_grad_slots():
+    """LinearFn with `.grad` pre-pointed at a buffer (FlatAdamW's layout): the backward kernels add into it and autograd gets
+    None; without a slot the gradients come back as tensors -- both equal torch autograd of F.linear."""
+    from mumpy_hip import autograd as AG
+    x = seeded_randn(1, 2, 196, 96)
+    w, b = (seeded_randn(2, 288, 96) / 96 ** 0.5), seeded_randn(3, 288)
+    g = seeded_randn(4, 2, 196, 288)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    F.linear(xr, wr, br).backward(g)
+    for slots in (False, True):
+        xd = x.cuda().requires_grad_(True)
+        wd, bd = torch.nn.Parameter(w.cuda()), torch.nn.Parameter(b.cuda())
+        if slots:
+            wd.grad, bd.grad = torch.full_like(wd, 0.5), torch.full_like(bd, -0.25)
+        AG.LinearFn.apply(xd, wd, bd).backward(g.cuda())
+        off_w, off_b = (0.5, -0.25) if slots else (0.0, 0.0)
+        assert rel_err(xd.grad.cpu(), xr.grad) < 2e-5
+        assert rel_err(wd.grad.cpu() - off_w, wr.grad) < 2e-5 and rel_err(bd.grad.cpu() - off_b, br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_gelu_fwd_bwd():
+    from mumpy_hip import ops
+    x = (seeded_randn(5, 4096) * 3).requires_grad_(True)
+    dy = seeded_randn(6, 4096)
+    y = F.gelu(x)
+    y.backward(dy)
+    assert rel_err(ops.gelu(x.detach().cuda()).cpu(), y.detach()) < 2e-6
+    assert rel_err(ops.gelu_bwd(x.detach().cuda(), dy.cuda()).cpu(), x.grad) < 5e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("r,c", [(392, 96), (64, 64), (1, 7), (1000, 333)])
+def test_hip_transpose_and_col_sum(r, c):
+    from mumpy_hip import ops
+    x = seeded_randn(7, r, c)
+    assert torch.equal(ops.transpose(x.cuda()).cpu(), x.t().contiguous())
+    t32 = ops.transpose(x.cuda(), 32).cpu()
+    rp = (r + 31) // 32 * 32
+    assert t32.shape == (c, rp) and torch.equal(t32[:, :r], x.t()) and not t32[:, r:].any()
+    assert rel_err(ops.col_sum(x.cuda()).cpu(), x.double().sum(0).float()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("m,n,k", [(392, 288, 96), (100, 96, 384)])
+def test_hip_linear_backward(m, n, k):
+    from mumpy_hip.autograd import LinearFn
+    x, w, b = seeded_randn(8, m, k), seeded_randn(9, n, k) / k ** 0.5, seeded_randn(10, n)
+    dy = seeded_randn(11, m, n)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    F.linear(xr, wr, br).backward(dy)
+    xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    LinearFn.apply(xg, wg, bg).backward(dy.cuda())
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(wg.grad.cpu(), wr.grad) < 1e-5 and rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shift", [0, 3])
+@pytest.mark.parametrize("b,hs,w,c", [(2, 14, 14, 96), (1, 28, 14, 64), (3, 7, 7, 32), (2, 280, 56, 128)])
+def test_hip_window_attention_bwd_vs_oracle(b, hs, w, c, shift):
+    """qkv / bias-table gradients of the attention core against autograd on the oracle's window_attention."""
+    from models.modules.swinTransformer import relative_position_index
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import WindowAttentionFn
+    if min(hs, w) <= 7:
+        shift = 0
+    nh = c // 32
+    l = hs * w
+    qkv = seeded_randn(20, b, l, 3 * c)
+    table = seeded_randn(21, 169, nh) * 0.2
+    dout = seeded_randn(22, b, l, c)
+    idx = relative_position_index(7, 7)
+    mask = O.shift_attn_mask(hs, w, shift) if shift else None
+    # oracle: attention core on pre-computed qkv (identity qkv / proj weights would cost a GEMM; restate the core directly)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    out = O.window_attention_core(qr, tr, idx, hs, w, shift, mask)
+    out.backward(dout)
+    qg, tg = qkv.cuda().requires_grad_(True), table.cuda().requires_grad_(True)
+    tab, ids = ops.compact_attn_mask(mask.cuda()) if mask is not None else (None, None)
+    y = WindowAttentionFn.apply(qg, tg, idx.cuda(), (b, hs, w, c, shift, 32 ** -0.5), tab, ids)
+    assert rel_err(y.detach().cpu(), out.detach()) < 1e-5
+    y.backward(dout.cuda())
+    assert rel_err(qg.grad.cpu(), qr.grad) < 2e-5
+    assert rel_err(tg.grad.cpu(), tr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,shift", TAGS)
+def test_hip_swin_block_backward_matches_reference(train_golden, tag, shift):
+    from mumpy_hip.autograd import swin_block_train
+    blk = _block(shift).cuda()
+    x = seeded_randn(700 + shift, 2, 196, 96).cuda().requires_grad_(True)
+    g = seeded_randn(710 + shift, 2, 196, 96).cuda()
+    y = swin_block_train(blk, x)
+    (y * g).sum().backward()
+    assert rel_err(y.detach().cpu(), train_golden[tag + "/y"]) < 1e-4
+    assert rel_err(x.grad.cpu(), train_golden[tag + "/dx"]) < GRAD_TOL
+    for name, prm in blk.named_parameters():
+        assert prm.grad is not None, name
+        assert rel_err(prm.grad.cpu(), train_golden[f"{tag}/grad/{name}"]) < GRAD_TOL, name
+
+
+@pytest.mark.gpu
+def test_hip_baseline_encoder_backward_vs_oracle():
+    """config 1's encoder (Swin-B, 24 blocks, 3 patch mergings, tokenizer): gradients of EVERY parameter and of the input
+    patches' consumer against torch autograd on the (reference-pinned) oracle, B=1."""
+    from models.encoder.encoder import BaselineEncoder
+    from mumpy_hip.autograd import baseline_encoder_train
+    enc = fill_module_(BaselineEncoder()).eval()
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "attn_mask" not in k else v)
+          for k, v in enc.state_dict().items()}
+    x = seeded_randn(800, 1, 3, 3, 224, 224)
+    g = seeded_randn(801, 1, 1024, 7, 7)
+    yo = O.baseline_encoder_forward(sd, x)
+    (yo * g).sum().backward()
+    enc = enc.cuda()
+    y = baseline_encoder_train(enc, x.cuda())
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 1e-4
+    worst = ("", 0.0)
+    for name, prm in enc.named_parameters():
+        assert prm.grad is not None, name
+        e = rel_err(prm.grad.cpu(), sd[name].grad)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] < 1e-3, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w,c,g", [(2, 14, 14, 256, 32), (1, 7, 9, 64, 8)])
+def test_hip_groupnorm_relu_bwd(b, h, w, c, g):
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import GroupNormActFn
+    z = seeded_randn(30, b, c, h, w) * 2 + 0.3
+    gm, bt, dy = 1 + 0.1 * seeded_randn(31, c), 0.1 * seeded_randn(32, c), seeded_randn(33, b, c, h, w)
+    zr, gr, br = [t.clone().requires_grad_(True) for t in (z, gm, bt)]
+    F.relu(F.group_norm(zr, g, gr, br, 1e-5)).backward(dy)
+    zg = z.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gg, bg = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    GroupNormActFn.apply(zg, gg, bg, g, 1e-5, ops.ACT_RELU).backward(dy.cuda())
+    assert rel_err(zg.grad.cpu(), zr.grad) < 5e-5 and rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("align", [True, False])
+@pytest.mark.parametrize("b,h,w,c", [(2, 7, 7, 64), (1, 14, 9, 32)])
+def test_hip_upsample2x_bwd(b, h, w, c, align):
+    from mumpy_hip import ops
+    x = seeded_randn(34, b, c, h, w).requires_grad_(True)
+    dy = seeded_randn(35, b, c, 2 * h, 2 * w)
+    F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=align).backward(dy)
+    dx = ops.upsample2x_bwd(dy.cuda().contiguous(memory_format=torch.channels_last), align)
+    assert rel_err(dx.cpu(), x.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w,cin,cout", [(2, 14, 14, 64, 32), (1, 7, 7, 256, 64)])
+def test_hip_conv3x3_backward(b, h, w, cin, cout):
+    from mumpy_hip.autograd import Conv2dFn
+    x, wt, bs = seeded_randn(36, b, cin, h, w), seeded_randn(37, cout, cin, 3, 3) / (9 * cin) ** 0.5, seeded_randn(38, cout)
+    dy = seeded_randn(39, b, cout, h, w)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, wt, bs)]
+    F.conv2d(xr, wr, br, padding=1).backward(dy)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = wt.cuda().requires_grad_(True), bs.cuda().requires_grad_(True)
+    Conv2dFn.apply(xg, wg.permute(0, 2, 3, 1).contiguous(), bg).backward(dy.cuda())
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5 and rel_err(wg.grad.cpu(), wr.grad) < 2e-5 and rel_err(bg.grad.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+def test_hip_baseline_decoder_backward_vs_oracle():
+    """config 1's decoder: logits and every parameter gradient against autograd on the oracle (B=2)."""
+    from models.decoder.decoder import BaselineDecoder
+    from mumpy_hip.autograd import baseline_decoder_train
+    dec = fill_module_(BaselineDecoder(in_channels=1024)).eval()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    x = seeded_randn(810, 2, 1024, 7, 7)
+    g = seeded_randn(811, 2, 1, 224, 224)
+    xo = x.clone().requires_grad_(True)
+    zo = O.baseline_decoder_forward(sd, xo)
+    (zo * g).sum().backward()
+    dec = dec.cuda()
+    xg = x.cuda().requires_grad_(True)
+    z = baseline_decoder_train(dec, xg)
+    (z * g.cuda()).sum().backward()
+    assert rel_err(z.detach().cpu(), zo.detach()) < 1e-4
+    # five GroupNorm+ReLU stages: a pre-activation within fp32 round-off of 0 can land on the other side of the ReLU in
+    # the two implementations, so the bound is looser than for a single kernel (measured 6e-4 on the input gradient)
+    assert rel_err(xg.grad.cpu(), xo.grad) < 2e-3
+    for name, prm in dec.named_parameters():
+        assert prm.grad is not None, name
+        assert rel_err(prm.grad.cpu(), sd[name].grad) < 2e-3, name
+
+
+@pytest.mark.gpu
+def test_hip_config1_training_steps_reduce_the_loss():
+    """config 1 end to end on the HIP kernels: BaselineEncoder -> BaselineDecoder -> mask loss -> backward -> fused AdamW,
+    a few steps on one synthetic clip; the loss of the reference's objective (softIoU + focal) must go down, and the first
+    step's loss and logits gradient equal the oracle's."""
+    from models.decoder.decoder import BaselineDecoder
+    from models.encoder.encoder import BaselineEncoder
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import baseline_decoder_train, baseline_encoder_train
+    from mumpy_hip.train import build_optimizers
+    enc, dec = fill_module_(BaselineEncoder()).eval().cuda(), fill_module_(BaselineDecoder(in_channels=1024)).eval().cuda()
+    opts = build_optimizers(enc, dec, lr_cnn=1e-6, lr=1e-5, weight_decay=1e-4, weight_decay_cnn=1e-4)
+    assert set(opts) == {"enc", "dec"}                       # the single-scale encoder has no cross-view ("cva") parameters
+    x = seeded_randn(820, 1, 3, 3, 224, 224).cuda()
+    target = torch.zeros(1, 1, 224, 224)
+    target[:, :, 60:150, 80:190] = 1.0
+    target = target.cuda()
+    losses = []
+    for it in range(6):
+        logits = baseline_decoder_train(dec, baseline_encoder_train(enc, x))
+        loss3, dlogits = ops.mask_loss(logits.detach(), target)
+        if it == 0:
+            zo = logits.detach().cpu().requires_grad_(True)
+            tot, _, _ = O.mask_loss(zo, target.cpu())
+            tot.backward()
+            assert abs(float(loss3[0]) - float(tot.detach())) < 1e-5 and rel_err(dlogits.cpu(), zo.grad) < 1e-4
+        logits.backward(dlogits)
+        for o in opts.values():
+            o.step()
+            o.zero_grad()
+        losses.append(float(loss3[0]))
+    assert losses[-1] < losses[0] and min(losses[3:]) < losses[0] - 0.02, losses
+    # inference after training sees the updated weights (derived-tensor caches are keyed on the optimizer's epoch)
+    with torch.no_grad():
+        z_inf = dec(enc(x))
+        z_trn = baseline_decoder_train(dec, baseline_encoder_train(enc, x))
+    assert rel_err(z_inf.cpu(), z_trn.cpu()) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_drop_path_train_mode():
+    """Stochastic depth (swin:302,305): per-sample Bernoulli(keep)/keep scaling, identity in eval mode; the Function and its
+    backward against x * scale, and a Swin block in train mode drops whole residual branches per sample."""
+    from models.modules.layers import DropPath
+    from mumpy_hip.autograd import DropPathFn, drop_path_train, swin_block_train
+    x = seeded_randn(40, 6, 49, 32).cuda().requires_grad_(True)
+    scale = torch.tensor([0.0, 1.25, 1.25, 0.0, 1.25, 1.25]).cuda()
+    y = DropPathFn.apply(x, scale)
+    assert torch.equal(y, x.detach() * scale.view(-1, 1, 1))
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, scale.view(-1, 1, 1).expand_as(x))
+    dp = DropPath(0.5)
+    dp.eval()
+    assert drop_path_train(dp, x) is x
+    dp.train()
+    torch.manual_seed(0)
+    out = drop_path_train(dp, torch.ones(4096, 4, device="cuda"))
+    vals = set(out[:, 0].unique().tolist())
+    assert vals == {0.0, 2.0} and 0.4 < float((out[:, 0] > 0).float().mean()) < 0.6
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blk = fill_module_(SwinTransformerBlock(dim=32, input_resolution=(7, 7), num_heads=1, window_size=7, drop_path=0.999)).cuda()
+    blk.train()
+    xin = seeded_randn(41, 5, 49, 32).cuda()
+    torch.manual_seed(1)                                           # fixed generator state: the draw below is reproducible
+    assert torch.equal(swin_block_train(blk, xin), xin)            # keep = 0.001: both branches dropped for every sample
+
+
+@pytest.mark.gpu
+def test_hip_cross_block_drop_path_train_mode():
+    """Train-mode parity of the cross-view branch (mTVE:138, 286): CVAModule drops the deformable output per WINDOW, the
+    block then drops the window-major sum per clip.  (i) block rate ~1: all three residual branches vanish, x1 comes back
+    unchanged (without the second wrap x1 + y would survive); (ii) CVA rate ~1, block rate 0: the result equals the eval
+    forward of the same block with a zeroed deformable branch; (iii) the masks are drawn per window / per clip, in the
+    reference's order, from torch's generator."""
+    from models.encoder.multiTemporalViewEncoder import CrossSwinBlock
+    from models.modules.layers import DropPath
+    from mumpy_hip.autograd import cross_swin_block_train
+    blk = fill_module_(CrossSwinBlock(96, 128, (14, 14), 3, temporal_dims=1, drop_path=0.5), "csb/").cuda()
+    assert isinstance(blk.drop_path, DropPath) and isinstance(blk.cva.drop_path, DropPath)
+    x1, x2 = seeded_randn(50, 4, 196, 96).cuda(), seeded_randn(51, 4, 196, 128).cuda()
+    blk.eval()
+    with torch.no_grad():
+        y_eval, out_eval = cross_swin_block_train(blk, x1, x2)
+    blk.train()
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.999999, 0.0
+    torch.manual_seed(2)
+    with torch.no_grad():
+        y, out = cross_swin_block_train(blk, x1, x2)
+    assert torch.equal(y, x1) and torch.equal(out, out_eval)                    # (i)
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.0, 0.999999
+    torch.manual_seed(2)
+    with torch.no_grad():
+        y = cross_swin_block_train(blk, x1, x2)[0]
+    blk.eval()
+    saved = (blk.cva.crossattn.proj_out.weight.detach().clone(), blk.cva.crossattn.proj_out.bias.detach().clone())
+    with torch.no_grad():
+        blk.cva.crossattn.proj_out.weight.zero_(); blk.cva.crossattn.proj_out.bias.zero_()
+        from mumpy_hip.state import bump_weights_epoch
+        bump_weights_epoch()
+        y_nod = cross_swin_block_train(blk, x1, x2)[0]
+        blk.cva.crossattn.proj_out.weight.copy_(saved[0]); blk.cva.crossattn.proj_out.bias.copy_(saved[1])
+        bump_weights_epoch()
+    assert rel_err(y.cpu(), y_nod.cpu()) < 1e-6 and rel_err(y.cpu(), y_eval.cpu()) > 1e-3      # (ii)
+    # (iii) draw order and mask shapes: block [B] on the W-MSA output, CVA [B*nW] on D, block [B] on y, block [B] on the MLP
+    blk.train()
+    blk.drop_path.drop_prob, blk.cva.drop_path.drop_prob = 0.5, 0.5
+    calls = []
+    import mumpy_hip.autograd as A
+    orig = A.DropPathFn.apply
+
+    def spy(x, scale):
+        calls.append((tuple(x.shape), scale.clone()))
+        return orig(x, scale)
+    A.DropPathFn.apply = spy
+    try:
+        torch.manual_seed(3)
+        with torch.no_grad():
+            cross_swin_block_train(blk, x1, x2)
+    finally:
+        A.DropPathFn.apply = orig
+    assert [c[0] for c in calls] == [(4, 196, 96), (16, 49, 96), (4, 196, 96), (4, 196, 96)]
+    torch.manual_seed(3)
+    for shape, scale in calls:                       # the same stream of Bernoulli(keep)/keep draws timm's drop_path makes
+        ref = torch.empty(shape[0], device="cuda").bernoulli_(0.5).div_(0.5)
+        assert torch.equal(scale, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("t", [1, 3, 5, 16])
+def test_hip_global_block_backward_vs_oracle(t):
+    """Global temporal ViT block (row 13): output, input gradient and every parameter gradient against autograd on the
+    oracle's global_block, S = 2*49 sites, T temporal tokens."""
+    from models.modules.blocks import Block
+    from mumpy_hip.autograd import global_block_train
+    blk = fill_module_(Block(dim=768, heads=12, mlp_dim=3072, dropout=0.0, drop_path=0.0)).eval()
+    sd = {"g." + k: v.detach().clone().requires_grad_(True) for k, v in blk.state_dict().items()}
+    x = seeded_randn(50 + t, 98, t, 768)
+    g = seeded_randn(70 + t, 98, t, 768)
+    xo = x.clone().requires_grad_(True)
+    yo = O.global_block(xo, sd, "g", 12)
+    (yo * g).sum().backward()
+    blk = blk.cuda()
+    xg = x.cuda().requires_grad_(True)
+    y = global_block_train(blk, xg)
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 2e-5
+    assert rel_err(xg.grad.cpu(), xo.grad) < 1e-4
+    for name, prm in blk.named_parameters():
+        assert rel_err(prm.grad.cpu(), sd["g." + name].grad) < 1e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scale,align", [(2, False), (4, False), (2, True)])
+def test_hip_upsample_bwd_scales(scale, align):
+    from mumpy_hip import ops
+    x = seeded_randn(60, 2, 32, 7, 7).requires_grad_(True)
+    dy = seeded_randn(61, 2, 32, 7 * scale, 7 * scale)
+    F.interpolate(x, scale_factor=scale, mode="bilinear", align_corners=align).backward(dy)
+    dx = ops.upsample_bwd(dy.cuda().contiguous(memory_format=torch.channels_last), scale, align)
+    assert rel_err(dx.cpu(), x.grad) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_groupnorm_sigmoid_bwd():
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import GroupNormActFn
+    z, gm, bt = seeded_randn(62, 2, 128, 14, 14) * 2, 1 + 0.1 * seeded_randn(63, 128), 0.1 * seeded_randn(64, 128)
+    dy = seeded_randn(65, 2, 128, 14, 14)
+    zr, gr, br = [t.clone().requires_grad_(True) for t in (z, gm, bt)]
+    torch.sigmoid(F.group_norm(zr, 8, gr, br, 1e-5)).backward(dy)
+    zg = z.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gg, bg = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    GroupNormActFn.apply(zg, gg, bg, 8, 1e-5, ops.ACT_SIGMOID).backward(dy.cuda())
+    assert rel_err(zg.grad.cpu(), zr.grad) < 5e-5 and rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+@pytest.mark.gpu
+def test_hip_pyramid_decoder_backward_vs_oracle():
+    """The multi-pyramid Decoder (row 15) at B=1, T=3: logits, features and every parameter gradient, plus the gradients
+    flowing back into the encoder outputs (final tokens, the 12 view tensors, the DCT features), against the oracle."""
+    from models.decoder.decoder import Decoder
+    from mumpy_hip.autograd import decoder_train
+    dec = fill_module_(Decoder()).eval()
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in dec.state_dict().items()}
+    chans = [(96, 96, 128), (192, 192, 256), (384, 384, 512), (768, 768, 1024)]
+    lens = [3136, 784, 196, 49]
+    x = seeded_randn(900, 1, 2304, 7, 7)
+    vx = [[seeded_randn(901 + 10 * s + v, 1, 1, lens[s] * (3 if v == 2 else 1), chans[s][v]) for v in range(3)] for s in range(4)]
+    ff = seeded_randn(950, 1, 9, 224, 224)
+    g = seeded_randn(951, 1, 1, 224, 224)
+    leaves_o = [x.clone().requires_grad_(True), [[t.clone().requires_grad_(True) for t in st] for st in vx], ff.clone().requires_grad_(True)]
+    lo, fo = O.decoder_forward(sd, leaves_o[0], leaves_o[1], leaves_o[2], [1, 1, 3])
+    (lo * g).sum().backward()
+    dec = dec.cuda()
+    leaves_g = [x.cuda().requires_grad_(True), [[t.cuda().requires_grad_(True) for t in st] for st in vx], ff.cuda().requires_grad_(True)]
+    lg, fg = decoder_train(dec, leaves_g[0], leaves_g[1], leaves_g[2])
+    (lg * g.cuda()).sum().backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 2e-4 and rel_err(fg.detach().cpu(), fo.detach()) < 2e-4
+    tol = 3e-3                                                  # ReLU / sigmoid chains over ~10 stages (see the baseline decoder test)
+    assert rel_err(leaves_g[0].grad.cpu(), leaves_o[0].grad) < tol
+    assert rel_err(leaves_g[2].grad.cpu(), leaves_o[2].grad) < tol
+    for s in range(4):
+        for v in range(3):
+            assert rel_err(leaves_g[1][s][v].grad.cpu(), leaves_o[1][s][v].grad) < tol, (s, v)
+    for name, prm in dec.named_parameters():
+        assert prm.grad is not None, name
+        assert rel_err(prm.grad.cpu(), sd[name].grad) < tol, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,c", [(6, 32), (3, 256), (5, 64)])
+def test_hip_dwconv5_window_fwd_bwd(n, c):
+    """first layer of conv_offset (deform:228): depthwise 5x5, padding 2, inside 7x7 windows."""
+    from mumpy_hip.autograd import DWConv5Fn
+    x, w, b, du = seeded_randn(100, n, 49, c), seeded_randn(101, c, 1, 5, 5) / 5, seeded_randn(102, c), seeded_randn(103, n, 49, c)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    ref = F.conv2d(xr.reshape(n, 7, 7, c).permute(0, 3, 1, 2), wr, br, padding=2, groups=c).permute(0, 2, 3, 1).reshape(n, 49, c)
+    ref.backward(du)
+    xg, wg, bg = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+    u = DWConv5Fn.apply(xg, wg, bg)
+    u.backward(du.cuda())
+    assert rel_err(u.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 1e-5 and rel_err(wg.grad.cpu(), wr.grad) < 1e-5 and rel_err(bg.grad.cpu(), br.grad) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nq,r,c", [(4, 1, 96), (2, 3, 192), (1, 5, 96), (3, 1, 768)])
+def test_hip_deform_sample_bwd(nq, r, c):
+    """grid_sample backward (deform:353-356) wrt the kv windows and the sampling positions, incl. points outside the window."""
+    from mumpy_hip.autograd import DeformSampleFn
+    b2 = nq * r
+    x2 = seeded_randn(110, b2, 49, c)
+    pos = (seeded_randn(111, nq, 3, 49, 2) * 0.7).clamp(-1.3, 1.3)          # some points fall outside [-1, 1]: zeros padding
+    ds = seeded_randn(112, b2, 49, c)
+    xr, pr = x2.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    ref = O.bilinear_sample_window(xr, pr[torch.arange(b2) % nq])
+    ref.backward(ds)
+    xg, pg = x2.cuda().requires_grad_(True), pos.cuda().requires_grad_(True)
+    out = DeformSampleFn.apply(xg, pg)
+    out.backward(ds.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5
+    assert rel_err(pg.grad.cpu(), pr.grad) < 5e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b1,r,c", [(4, 1, 96), (2, 3, 192), (1, 5, 96), (3, 3, 384)])
+def test_hip_deform_attention_bwd(b1, r, c):
+    """attention core of SwinDAttention (deform:360-395) in window form: pairing b2 % B1, r-tuple sum, scale on the product."""
+    from mumpy_hip.autograd import DeformAttentionFn
+    b2, nh = b1 * r, c // 32
+    q, kv, do = seeded_randn(120, b1, 49, c), seeded_randn(121, b2, 49, 2 * c), seeded_randn(122, b1, 49, c)
+    qr, kvr = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    sel = torch.arange(b2) % b1
+    qh = qr[sel].reshape(b2, 49, nh, 32).transpose(1, 2)
+    k = kvr[..., :c].reshape(b2, 49, nh, 32).transpose(1, 2)
+    v = kvr[..., c:].reshape(b2, 49, nh, 32).transpose(1, 2)
+    attn = ((qh @ k.transpose(-2, -1)) * 32 ** -0.5).softmax(-1)
+    ref = (attn @ v).transpose(1, 2).reshape(b2, 49, c).reshape(b1, r, 49, c).sum(1)
+    ref.backward(do)
+    qg, kvg = q.cuda().requires_grad_(True), kv.cuda().requires_grad_(True)
+    out = DeformAttentionFn.apply(qg, kvg, 32 ** -0.5)
+    out.backward(do.cuda())
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    assert rel_err(qg.grad.cpu(), qr.grad) < 2e-5 and rel_err(kvg.grad.cpu(), kvr.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b1,r,c", [(4, 1, 96), (2, 3, 192), (2, 5, 96)])
+def test_hip_swin_dattention_backward_vs_oracle(b1, r, c):
+    """Whole SwinDAttention module (row 10), window form: output, both input gradients and every parameter gradient against
+    autograd on the oracle's swin_dattention (index quirks included)."""
+    from models.modules.deformableAttention import SwinDAttention
+    from mumpy_hip.autograd import swin_dattention_train
+    att = fill_module_(SwinDAttention(c, c // 32, 0.0, 3)).eval()
+    sd = {"a." + k: v.detach().clone().requires_grad_(True) for k, v in att.state_dict().items()}
+    x1, x2, g = seeded_randn(130, b1, 49, c), seeded_randn(131, b1 * r, 49, c), seeded_randn(132, b1, 49, c)
+    x1o, x2o = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+    yo = O.swin_dattention(x1o, x2o, sd, "a")
+    (yo * g).sum().backward()
+    att = att.cuda()
+    x1g, x2g = x1.cuda().requires_grad_(True), x2.cuda().requires_grad_(True)
+    y = swin_dattention_train(att, x1g, x2g)
+    (y * g.cuda()).sum().backward()
+    assert rel_err(y.detach().cpu(), yo.detach()) < 2e-5
+    assert rel_err(x1g.grad.cpu(), x1o.grad) < 2e-4 and rel_err(x2g.grad.cpu(), x2o.grad) < 2e-4
+    for name, prm in att.named_parameters():
+        assert prm.grad is not None, name
+        if name == "proj_k.bias":       # adds the same q.b_k to every key's score: softmax-invariant, the true gradient is 0
+            assert float(prm.grad.abs().max()) < 1e-5 and float(sd["a." + name].grad.abs().max()) < 1e-5
+            continue
+        assert rel_err(prm.grad.cpu(), sd["a." + name].grad) < 2e-4, name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,t", [(1, 3), (2, 5)])
+def test_hip_full_model_backward_vs_oracle(b, t):
+    """The whole three-view model (Encoder + Decoder) trained through mumpy_hip.autograd: mask logits and EVERY parameter
+    gradient (1085 encoder + 98 decoder parameters) against autograd on the reference-pinned oracle.  (1,3) is the canonical
+    graph; (2,5) is the north-star shape per clip (tubelets (5,4,1), r = 5 in the view-2 cross attention) with two clips in
+    the micro-batch, so the cross-sample coupling of SwinDAttention (deform:330,394) is differentiated too."""
+    from models.decoder.decoder import Decoder
+    from models.encoder.encoder import Encoder
+    from mumpy_hip.autograd import decoder_train, encoder_train
+    enc, dec = fill_module_(Encoder(num_frames=t)).eval(), fill_module_(Decoder(input_token_temporal_dims=[1, 1, t])).eval()
+
+    def leaf_sd(mod):
+        return {k: (v.detach().clone().requires_grad_(True) if v.dtype.is_floating_point and "attn_mask" not in k else v)
+                for k, v in mod.state_dict().items()}
+    sde, sdd = leaf_sd(enc), leaf_sd(dec)
+    x = seeded_randn(990, b, t, 3, 224, 224)
+    g = seeded_randn(991, b, 1, 224, 224)
+    lo = O.full_forward(sde, sdd, x)[0]
+    (lo * g).sum().backward()
+    enc, dec = enc.cuda(), dec.cuda()
+    fx, vx, dx = encoder_train(enc, x.cuda())
+    lg, _ = decoder_train(dec, fx, vx, dx)
+    (lg * g.cuda()).sum().backward()
+    assert rel_err(lg.detach().cpu(), lo.detach()) < 1e-3
+    bad = []
+    for mod, sd in ((enc, sde), (dec, sdd)):
+        for name, prm in mod.named_parameters():
+            assert prm.grad is not None, name
+            ref = sd[name].grad
+            if name.endswith("crossattn.proj_k.bias"):          # softmax-invariant: true gradient 0
+                assert float(prm.grad.abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()) * 1e4), name
+                continue
+            e = rel_err(prm.grad.cpu(), ref)
+            if e > 1e-2:
+                bad.append((name, e))
+    assert not bad, bad[:10]

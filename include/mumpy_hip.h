@@ -53,6 +53,21 @@ extern "C" {
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);
 
+/* ---- LayerNorm folded into the GEMMs either side of it (round 3; swin:266,305: x + f(norm(x)) chains) ----
+ * A pre-norm block computes  y = act(LayerNorm(x) W^T + b)  right after a residual GEMM produced x.  Instead of a LayerNorm
+ * launch (one read + one write of x between two GEMMs):
+ *   producer  (stats_out != NULL): the residual GEMM's epilogue also writes, per output row and 128-column tile, {mean_t, M2_t} of
+ *             the values it stores -- stats_out (M, ceil(N/128), 2), two-pass inside the tile (no cancellation);
+ *   consumer  (ln_stats != NULL): x is the RAW x, W is W diag(gamma) (caller-prepared), bias is W beta + b, ln_colsum[n] =
+ *             sum_k W[n][k] gamma[k]; the epilogue finishes  rstd (acc - mean colsum) + bias  with mean / rstd of the row combined
+ *             from the producer's ln_gn = ceil(K/128) partials (Chan's parallel update: stable), eps = ln_eps; no residual.
+ * Both run only on the persistent 128x128 kernel: mumpy_linear_ln_tiles(M,N,K) > 0 says a shape takes it (and is the tile count);
+ * otherwise MUMPY_EINVAL.  workspace: the kept, zero-initialised workspace of mumpy_linear_wsz_fwd (required).  fp32 math only. */
+int mumpy_linear_ln_tiles(int64_t M, int N, int K);
+int mumpy_linear_lnx_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N, int K,
+                         int act, void* workspace, int64_t workspace_bytes, float* stats_out, const float* ln_stats, int ln_gn,
+                         const float* ln_colsum, float ln_eps, void* stream);
+
 /* ---- SwinDAttention with the index work folded into its GEMMs (round 3; csrc/cva_fused.hip) ----
  * kv = [proj_k | proj_v](grid_sample(x2, pos)) (deform:353-362) in ONE launch: the bilinear sampling (align_corners=True, zeros
  * padding, per-group positions, kv window i pairs with q window i mod nq) is the A-operand loader of the projection; the sampled

@@ -715,9 +715,49 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split, bool x3 = false) {
     return p;
 }
 
+int device_cus() {
+    static int num_cu = 0;
+    if (!num_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
+        else num_cu = NUM_CU;
+    }
+    return num_cu;
+}
+
+// Which schedule of the persistent wave-specialised kernel (gemm_ws.h) an eligible fp32 shape takes: 0 = none (the 64x64
+// persistent kernel or the tiled kernels), 1 = whole tiles, 2 = split ("stream-K").  MUMPY_GEMM_WS=0 disables it, =1 forces it
+// for every eligible shape, =3 forces the split schedule wherever a workspace is given (both: tuning).  Default, fitted to
+// same-device A/B runs of tools/gemm_shapes.py over the model's shapes: take it when whole 128x128 tiles fill >= 86 % of the
+// rounds they need (K >= 128), or -- with a workspace -- when an even split of the chunk sequence gives every CU >= 24 chunks
+// and cuts a tile into <= 3 parts; leave the deep-K shapes with two or more tiles per CU to the tiled kernels (two co-resident
+// workgroups hide each other's prologue and epilogue there: 121 TFLOP/s).
+int ws_plan(int64_t M, int N, int K, bool have_ws, bool conv) {
+    static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
+    const int num_cu = device_cus();
+    const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int nk = K / 32;
+    const double rounds = (double)tiles / num_cu, eff = rounds / (double)((tiles + num_cu - 1) / num_cu);
+    const double per_cu = (double)tiles * nk / num_cu;                 // chunks per CU under an even split
+    int how = 0;
+    if (ws_mode == 1) how = 1;
+    else if (ws_mode == 3) how = have_ws ? 2 : 1;
+    else if (ws_mode == 2 && conv) {
+        // convolutions (decoder: N = 128 / 256, 196 or 784 tiles = 0.77 of the rounds they need): the even split first,
+        // whole tiles down to 75 % round utilisation (profiles/r02_conv_shapes.txt; the tiled kernels sit at 74-80 TFLOP/s)
+        if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0) how = 2;
+        else if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.75 && K >= 128) how = 1;
+    } else if (ws_mode == 2) {
+        if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.86 && K >= 128 && !(K >= 1024 && rounds >= 1.8)) how = 1;
+        else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
+    }
+    return how;
+}
+
 int launch_linear(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0,
-                  const ConvGeom* conv = nullptr, bool ws_clean = false) {
+                  const ConvGeom* conv = nullptr, bool ws_clean = false, const gemm_ws::LnArgs* ln = nullptr) {
     if (rpb <= 0) { rpb = M; bstride = 0; }
     const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
     const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
@@ -731,32 +771,16 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     // sequence gives every CU >= 24 chunks and cuts a tile into <= 3 parts; leave the deep-K shapes with two or more tiles
     // per CU to the tiled kernels (two co-resident workgroups hide each other's prologue and epilogue there: 121 TFLOP/s).
     const gemm_ws::Conv cvd{cg.H, cg.W, cg.Cin, cg.kh, cg.kw};
+    if (ln && (rpb < M || math_bf16 || math_x3 || conv || !gemm_ws::eligible(M, N, K) ||
+               !ws_plan(M, N, K, ws && ws_bytes >= gemm_ws::workspace_bytes(device_cus()), false))) {
+        set_error("linear: LayerNorm folding needs a shape the persistent 128x128 kernel takes (mumpy_linear_ln_tiles) in fp32 mode");
+        return MUMPY_EINVAL;
+    }
     if (rpb >= M && !math_bf16 && !math_x3 && (conv ? gemm_ws::conv_eligible(M, N, cvd) : gemm_ws::eligible(M, N, K))) {
-        static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
-        static int num_cu = 0;
-        if (!num_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) num_cu = prop.multiProcessorCount;
-            else num_cu = NUM_CU;
-        }
-        const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
-        const int nk = K / 32;
-        const double rounds = (double)tiles / num_cu, eff = rounds / (double)((tiles + num_cu - 1) / num_cu);
-        const double per_cu = (double)tiles * nk / num_cu;                 // chunks per CU under an even split
+        const int num_cu = device_cus();
         const bool have_ws = ws && ws_bytes >= gemm_ws::workspace_bytes(num_cu);
-        int how = 0;                                                        // 0: tiled kernels, 1: whole tiles, 2: split
-        if (ws_mode == 1) how = 1;
-        else if (ws_mode == 3) how = have_ws ? 2 : 1;
-        else if (ws_mode == 2 && conv) {
-            // convolutions (decoder: N = 128 / 256, 196 or 784 tiles = 0.77 of the rounds they need): the even split first,
-            // whole tiles down to 75 % round utilisation (profiles/r02_conv_shapes.txt; the tiled kernels sit at 74-80 TFLOP/s)
-            if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0) how = 2;
-            else if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.75 && K >= 128) how = 1;
-        } else if (ws_mode == 2) {
-            if (tiles >= (int64_t)(0.75 * num_cu) && eff >= 0.86 && K >= 128 && !(K >= 1024 && rounds >= 1.8)) how = 1;
-            else if (have_ws && eff < 0.86 && per_cu >= 24.0 && (double)nk / per_cu <= 3.0 && !(K >= 1024 && rounds >= 1.8)) how = 2;
-        }
+        const int how = ws_plan(M, N, K, have_ws, conv != nullptr);           // 0: tiled kernels, 1: whole tiles, 2: split
+        const int nk = K / 32;
         // Mid-size shapes without a GELU epilogue: the same design at 64x64 tiles, two workgroups per CU (gemm_ws64.h).  Fitted
         // to same-device runs of tools/gemm_shapes.py with MUMPY_GEMM_WS64 = 0 / 1 / 2 (profiles/r02_gemm_ws64_shapes.txt): it
         // wins up to 32 chunks deep when the tiles fill at most one round of the 2 x CUs slots or at least 2.5, and for the
@@ -775,7 +799,7 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
         }
         if (how) {
             if (int rc = gemm_ws::launch(x, W, bias, residual, y, M, N, K, act, num_cu, s, ws, ws_bytes, how == 2 ? 1 : 0, nullptr, ws_clean,
-                                         conv ? &cvd : nullptr)) return rc;
+                                         conv ? &cvd : nullptr, ln)) return rc;
             MUMPY_CHECK_LAUNCH("linear(ws)");
             return 0;
         }
@@ -974,6 +998,32 @@ extern "C" int mumpy_linear_wsz_fwd(const float* x, const float* W, const float*
     MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "linear: workspace must be 16-byte aligned");
     return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream), 0, 0, nullptr, true);
+}
+
+// ---- LayerNorm folded into the GEMMs either side of it (gemm_ws.h, epilogue_role<.., LN>) ------------------------------------
+// Column tiles (ceil(N / 128)) of a shape that an fp32 launch WITH a kept workspace runs on the persistent 128x128 kernel -- the
+// only kernel whose epilogue can emit / consume the per-tile row statistics -- or 0.
+extern "C" int mumpy_linear_ln_tiles(int64_t M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK || N % 32 || !gemm_ws::eligible(M, N, K)) return 0;
+    return ws_plan(M, N, K, true, false) ? (N + 127) / 128 : 0;
+}
+
+extern "C" int mumpy_linear_lnx_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M,
+                                    int N, int K, int act, void* workspace, int64_t workspace_bytes, float* stats_out,
+                                    const float* ln_stats, int ln_gn, const float* ln_colsum, float ln_eps, void* stream) {
+    if (M == 0) return 0;
+    if (int rc = check_linear_args(x, W, residual, y, M, N, K, act)) return rc;
+    MUMPY_REQUIRE((act & ~0xff) == 0, MUMPY_EINVAL, "linear_lnx: fp32 matrix math only");
+    MUMPY_REQUIRE(aligned16(workspace) && workspace, MUMPY_EALIGN, "linear_lnx: needs the kept (zeroed) workspace of mumpy_linear_wsz_fwd");
+    MUMPY_REQUIRE((stats_out != nullptr) != (ln_stats != nullptr), MUMPY_EINVAL, "linear_lnx: exactly one of stats_out (producer) / ln_stats (consumer)");
+    MUMPY_REQUIRE(!ln_stats || (ln_colsum && bias && !residual && ln_gn == (K + 127) / 128 && ln_gn <= 16 && ln_eps > 0.f), MUMPY_EINVAL,
+                  "linear_lnx: the consumer takes W gamma, colsum, bias = W beta + b, no residual, and ln_gn = ceil(K / 128) tiles (got %d)", ln_gn);
+    MUMPY_REQUIRE(aligned16(stats_out) && aligned16(ln_stats) && aligned16(ln_colsum), MUMPY_EALIGN, "linear_lnx: pointers must be 16-byte aligned");
+    MUMPY_REQUIRE(M * (int64_t)((N + 127) / 128) * 8 < (1ll << 31) && M * (int64_t)(ln_gn > 0 ? ln_gn : 1) * 8 < (1ll << 31), MUMPY_ERANGE,
+                  "linear_lnx: statistics buffer beyond 2 GiB");
+    const gemm_ws::LnArgs ln{stats_out, ln_stats, ln_colsum, ln_gn, K, ln_eps};
+    return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace), workspace_bytes, as_stream(stream), 0, 0,
+                         nullptr, true, &ln);
 }
 
 extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, const float* W,

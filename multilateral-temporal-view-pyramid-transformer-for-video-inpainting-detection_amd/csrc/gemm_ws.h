@@ -75,6 +75,16 @@ struct Params {
     unsigned cv_mhw, cv_shw, cv_mw, cv_sw;                  // magic numbers: m / (H W) and rem / W as mulhi + shift
     unsigned* flags;       // [grid] arrival flags of the partial slabs (zeroed by the launcher), or null: whole tiles only
     float* slabs;          // [grid][128*128] partial accumulator images of split tiles
+    // LayerNorm folded into the GEMMs either side of it (epilogue_role<.., LN>; swin:266,305, blocks:86-88):
+    //   LN = 1, producer (a residual GEMM whose output is the next LayerNorm's input): the epilogue also writes, per output row
+    //           and 128-column tile, {mean_t, M2_t} of the values it stores (two-pass inside the tile: no cancellation);
+    //   LN = 2, consumer (y = act(LayerNorm(x) W^T + b)): X is the RAW x, W is W diag(gamma), `bias` is W beta + b, and the
+    //           epilogue finishes  rstd (acc - mean * colsum) + bias  with mean / rstd combined (Chan) from the producer's partials.
+    float* stats_out;      // LN = 1: [M][gn][2]
+    const float* ln_stats; // LN = 2: [M][ln_gn][2] from the producer (ln_gn = its column tiles, ln_C = its N = this K)
+    const float* ln_colsum;  // LN = 2: [N] sum_k W[n][k] gamma[k]
+    int ln_gn, ln_C;
+    float ln_eps;
 #ifdef MUMPY_WS_STAMP
     unsigned long long* stamps;   // diagnostics build: [block][8] cycle sums
 #endif
@@ -442,7 +452,20 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
 // GELU pass, which fit the issue slots the MFMA stream leaves.  The pass code is unrolled with static register indices;
 // the chunks that remain of a tile only join the barrier.
 // OUT16: y is bf16 (config 3's activation storage; no residual then): a pass packs its four values and stores 8 bytes.
-template <int P, bool OUT16 = false>
+// sum over the 32 lanes of this lane's half-wave (the lanes that share an epilogue row), result in all of them; ds_swizzle in
+// bit-mask mode (xor masks stay inside groups of 32): one LDS-crossbar instruction per step, no address arithmetic
+__device__ __forceinline__ float half_sum32(float x) {
+#define MUMPY_SWZ_XOR(k_) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), ((k_) << 10) | 0x1f))
+    x += MUMPY_SWZ_XOR(1);
+    x += MUMPY_SWZ_XOR(2);
+    x += MUMPY_SWZ_XOR(4);
+    x += MUMPY_SWZ_XOR(8);
+    x += MUMPY_SWZ_XOR(16);
+#undef MUMPY_SWZ_XOR
+    return x;
+}
+
+template <int P, bool OUT16 = false, int LN = 0>
 __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned b, unsigned G, unsigned u0, unsigned u1, int hl) {
     constexpr uint32_t OSZ = OUT16 ? 2u : 4u;
     const float* const E = lds + E_OFF_DW;
@@ -459,6 +482,17 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
     f32x4 rv[PASSES], bias4;
     uint32_t yo[PASSES];                            // byte offsets of this lane's 16 output rows in y (tile in flight)
     const uint32_t row8 = 8u * (uint32_t)p.N * OSZ; // byte pitch of 8 rows of y
+    // LayerNorm folding (see Params)
+    const auto rs_st = __builtin_amdgcn_make_buffer_rsrc(LN == 1 ? p.stats_out : p.Y, 0, LN == 1 ? (int)((int64_t)p.M * p.gn * 8) : 0, 0x00020000);
+    const auto rs_ln = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LN == 2 ? p.ln_stats : p.Y), 0,
+                                                         LN == 2 ? (int)((int64_t)p.M * p.ln_gn * 8) : 0, 0x00020000);
+    const auto rs_cs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(LN == 2 ? p.ln_colsum : p.Y), 0, LN == 2 ? p.N * 4 : 0, 0x00020000);
+    uint32_t st_off = 0;                            // LN = 1: byte offset of {mean_t, M2_t} of this lane's first row in this tile
+    float st_inv = 0.f;                             //         1 / (valid columns of this tile)
+    bool st_valid = false;                          //         this lane's four columns are inside the matrix
+    float ln_mean = 0.f, ln_rstd = 0.f;             // LN = 2: statistics of row 8 (e_c4 & 15) + e_row of this tile (lane e holds row e's)
+    f32x4 cs4 = {0.f, 0.f, 0.f, 0.f};               //         column sums of W gamma for this lane's four columns
+    const int ln_lane4 = ((hl & 32)) * 4;           //         bpermute byte address of lane 0 of this half-wave
     // Rows past M need no predicate: their offsets are past the end of the buffer (num_records = M N 4) and the access is
     // dropped by the range check; columns past N start from the OOB offset.
     auto begin_tile = [&](unsigned t) {             // the tile whose image is being dumped: fetch its residual rows + bias
@@ -472,14 +506,58 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
             rv[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_r, yo[e], 0, 0));
         }
         bias4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_b, n < p.N ? (uint32_t)n * 4u : OOB, 0, 0));
+        if (LN == 1) {
+            const int nt = p.N - (int)tn * BN < BN ? p.N - (int)tn * BN : BN;
+            st_inv = 1.0f / (float)nt;
+            st_valid = n < p.N;
+            st_off = ((((uint32_t)tm * BM + e_row) * p.gn) + tn) * 8u;
+        }
+        if (LN == 2) {
+            cs4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_cs, n < p.N ? (uint32_t)n * 4u : OOB, 0, 0));
+            // lane j of a half-wave combines the partials of row 8 (j & 15) + e_row (Chan et al.: n, mean, M2 per column tile)
+            const uint32_t row = (uint32_t)tm * BM + 8u * (uint32_t)(e_c4 & 15) + (uint32_t)e_row;
+            const uint32_t base = row * (uint32_t)p.ln_gn * 8u;
+            float msum = 0.f;
+            for (int t = 0; t < p.ln_gn; ++t) {
+                const float nt = (float)(p.ln_C - t * BN < BN ? p.ln_C - t * BN : BN);
+                msum += nt * __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ln, base + 8u * t, 0, 0));
+            }
+            const float mean = msum / (float)p.ln_C;
+            float m2 = 0.f;
+            for (int t = 0; t < p.ln_gn; ++t) {
+                const float nt = (float)(p.ln_C - t * BN < BN ? p.ln_C - t * BN : BN);
+                const float mt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ln, base + 8u * t, 0, 0));
+                const float qt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ln, base + 8u * t + 4u, 0, 0));
+                const float d = mt - mean;
+                m2 += qt + nt * d * d;
+            }
+            ln_mean = mean;
+            ln_rstd = rsqrtf(m2 / (float)p.ln_C + p.ln_eps);
+        }
     };
     auto pass = [&](int e) {                        // e is a compile-time constant at every call site
-        f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * e + e_row) * BN + 4 * e_c4) + bias4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(E + (8 * e + e_row) * BN + 4 * e_c4);
+        if (LN == 2) {                              // LayerNorm(x) W^T = rstd (x (W gamma)^T - mean colsum) + (W beta + b)
+            const float mean = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln_lane4 + 4 * e, __builtin_bit_cast(int, ln_mean)));
+            const float rstd = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(ln_lane4 + 4 * e, __builtin_bit_cast(int, ln_rstd)));
+            v = rstd * (v - mean * cs4);
+        }
+        v += bias4;
         if (p.act == MUMPY_ACT_GELU) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) v[x] = gelu_erf(v[x]);
         }
         v += rv[e];
+        if (LN == 1) {                              // statistics of the stored values: mean over the tile's columns, then M2
+            const float mean_t = half_sum32(st_valid ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f) * st_inv;
+            const f32x4 d = v - mean_t;
+            const float m2 = half_sum32(st_valid ? (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]) : 0.f);
+            if (e_c4 == 0) {
+                typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                const u32x2 st = {__builtin_bit_cast(uint32_t, mean_t), __builtin_bit_cast(uint32_t, m2)};
+                __builtin_amdgcn_raw_buffer_store_b64(st, rs_st, st_off + (uint32_t)e * (8u * p.gn * 8u), 0, 0);
+            }
+        }
         if (OUT16) {
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
@@ -604,7 +682,7 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
 }
 
 // IO: 0 = fp32 operands and output; 1 = bf16 operands, bf16 output; 2 = bf16 operands, fp32 output (+ fp32 residual)
-template <int P, bool CONV = false, int IO = 0>
+template <int P, bool CONV = false, int IO = 0, int LN = 0>
 __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
     extern __shared__ __attribute__((aligned(1024))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -635,7 +713,7 @@ __global__ __launch_bounds__(768, 3) void gemm_ws_kernel(Params p) {
         // the few instructions of these roles are not additionally delayed by arbitration)
         if (!(DBG & 8)) __builtin_amdgcn_s_setprio(3);
         if (wave < 8) loader_role<CONV, IO != 0>(p, lds, t0, kc0, n_chunks, tid - 256);
-        else epilogue_role<P, IO == 1>(p, lds, b, G, u0, u1, tid - 512);
+        else epilogue_role<P, IO == 1, LN>(p, lds, b, G, u0, u1, tid - 512);
     }
 }
 
@@ -663,10 +741,24 @@ inline void magic_div(unsigned d, unsigned& magic, unsigned& shift) {
 // workspace for the split schedule: arrival flags + one slab per workgroup
 inline int64_t workspace_bytes(int num_cu) { return 4096 + (int64_t)num_cu * E_DW * 4; }
 
+// LayerNorm folding (Params): exactly one of stats_out (producer) / ln_stats (consumer) is set
+struct LnArgs {
+    float* stats_out;
+    const float* ln_stats;
+    const float* ln_colsum;
+    int ln_gn, ln_C;
+    float ln_eps;
+};
+
 inline int launch(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, int num_cu, hipStream_t s, void* ws = nullptr, int64_t ws_bytes = 0, int force_split = -1,
-                  void* stamps = nullptr, bool ws_clean = false, const Conv* cv = nullptr) {
+                  void* stamps = nullptr, bool ws_clean = false, const Conv* cv = nullptr, const LnArgs* ln = nullptr) {
     Params p;
+    p.stats_out = ln ? ln->stats_out : nullptr;
+    p.ln_stats = ln ? ln->ln_stats : nullptr;
+    p.ln_colsum = ln ? ln->ln_colsum : nullptr;
+    p.ln_gn = ln ? ln->ln_gn : 0; p.ln_C = ln ? ln->ln_C : 0; p.ln_eps = ln ? ln->ln_eps : 0.f;
+    const int ln_mode = !ln ? 0 : (ln->stats_out ? 1 : 2);
     p.cv_H = p.cv_W = p.cv_C = p.cv_kh = p.cv_kw = p.cv_cpc = 0;
     p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
     if (cv) {
@@ -727,7 +819,22 @@ inline int launch(const float* x, const float* W, const float* bias, const float
             if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
             attr_set_cv = true;                                                                                         \
         }                                                                                                               \
+        static bool attr_set_ln1 = false, attr_set_ln2 = false;                                                         \
+        if (ln_mode == 1 && !attr_set_ln1) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<P_, false, 0, 1>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
+            if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
+            attr_set_ln1 = true;                                                                                        \
+        }                                                                                                               \
+        if (ln_mode == 2 && !attr_set_ln2) {                                                                            \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ws_kernel<P_, false, 0, 2>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);                  \
+            if (e != hipSuccess) { set_error("gemm_ws: cannot reserve %d B of LDS: %s", LDS_BYTES, hipGetErrorString(e)); return (int)e; } \
+            attr_set_ln2 = true;                                                                                        \
+        }                                                                                                               \
         if (cv) hipLaunchKernelGGL((gemm_ws_kernel<P_, true>), dim3(grid), dim3(768), LDS_BYTES, s, p);                 \
+        else if (ln_mode == 1) hipLaunchKernelGGL((gemm_ws_kernel<P_, false, 0, 1>), dim3(grid), dim3(768), LDS_BYTES, s, p); \
+        else if (ln_mode == 2) hipLaunchKernelGGL((gemm_ws_kernel<P_, false, 0, 2>), dim3(grid), dim3(768), LDS_BYTES, s, p); \
         else hipLaunchKernelGGL((gemm_ws_kernel<P_, false>), dim3(grid), dim3(768), LDS_BYTES, s, p);                   \
     } while (0)
     if (P == 1) MUMPY_WS_LAUNCH(1);
@@ -752,6 +859,7 @@ inline int launch16(const void* x16, const void* W16, const float* bias, const f
     p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
     p.X = static_cast<const float*>(x16); p.W = static_cast<const float*>(W16); p.bias = bias; p.residual = residual;
     p.Y = static_cast<float*>(y);
+    p.stats_out = nullptr; p.ln_stats = nullptr; p.ln_colsum = nullptr; p.ln_gn = p.ln_C = 0; p.ln_eps = 0.f;
     p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / 64;
     p.gm = (unsigned)((M + BM - 1) / BM); p.gn = (unsigned)((N + BN - 1) / BN);
     p.tiles = p.gm * p.gn;

@@ -59,9 +59,10 @@ class CrossSwinBlock(nn.Module):
                                  attn_drop, drop_path, cur_stage)
         self.register_buffer("attn_mask", None)
 
-    def msa(self, x1):
+    def msa(self, x1, need_out=True):
         """First half: x1 + W-MSA(LN(x1)).  Returns (x1 after the residual, out = W-MSA output BEFORE the residual, which is
-        what the next view's cross attention consumes: mTVE:275, 347-349)."""
+        what the next view's cross attention consumes: mTVE:275, 347-349).  need_out=False (view 1: nobody consumes its `out`,
+        mTVE:349): the residual add rides in the projection's epilogue and `out` is None."""
         h, w = self.input_resolution
         b, l1, c1 = x1.shape
         if self.training:
@@ -72,6 +73,8 @@ class CrossSwinBlock(nn.Module):
             out = ops.linear_bf16s(a, _w16(self.attn, "proj"), self.attn.proj.bias, out_bf16=False)
             return ops.add(x1, out), out
         a = self.attn.attend(ops.layernorm(x1, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, l1 // w, w, 0, None)
+        if not need_out:
+            return ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x1), None
         out = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias)
         return ops.add(x1, out), out
 
@@ -96,7 +99,10 @@ class CrossSwinBlock(nn.Module):
             x1 = self.cva.crossattn.attend_combine(x1, x2p, b, hs1, w, hs2, prep)
         if ops.storage() == "bf16":
             return self.mlp.forward_bf16(ops.layernorm_bf16(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), x1)
-        return self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1)
+        # (fc2 leaves row statistics for the first plain block's norm1 when both GEMMs run on the persistent kernel)
+        m = b * l1
+        emit = ops.linear_ln_tiles(m, c1, self.mlp.fc2.in_features) > 0 and ops.linear_ln_tiles(m, 3 * c1, c1) > 0
+        return self.mlp(ops.layernorm(x1, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x1, emit_stats=emit)
 
     def forward(self, x1, x2):
         """x1 (B, t1*H*W, C1), x2 (B, t2*H*W, C2) raster.  Returns (x1_new, out)."""
@@ -154,7 +160,7 @@ class CrossThreeViewSwinBlock(nn.Module):
             sb.wait_event(fork)
             x[0].record_stream(sb)
             with torch.cuda.stream(sb):
-                x1a, _ = self.block1.msa(x[0])
+                x1a, _ = self.block1.msa(x[0], need_out=False)
                 prep1 = self.block1.prep(x1a)
                 sb.wait_event(e2)
                 out2.record_stream(sb)

@@ -6,7 +6,7 @@ launch for all sites and heads -> proj GEMM(+residual) -> LN -> fc1 GEMM(+GELU) 
 """
 import torch.nn as nn
 
-from models.modules.layers import DropPath, refuse_stochastic_depth
+from models.modules.layers import Derived, DropPath, refuse_stochastic_depth
 from mumpy_hip import ops
 
 
@@ -22,9 +22,9 @@ class FeedForward(nn.Module):
     def unwrapped(self):
         return self
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, emit_stats=False):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU)
-        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, emit_stats=emit_stats)
 
     def forward_bf16(self, x16, residual):
         """bf16 storage: bf16 LayerNorm output in, bf16 hidden tensor, fc2 adds into the fp32 residual stream."""
@@ -50,10 +50,18 @@ class Attention(nn.Module):
     def unwrapped(self):
         return self
 
-    def forward(self, x, mask=None, residual=None):
-        """x (S,T,C) -> (attention output after proj (+residual), None); the TxT map is not materialised."""
+    def forward(self, x, mask=None, residual=None, ln=None):
+        """x (S,T,C) -> (attention output after proj (+residual), None); the TxT map is not materialised.
+        ln = (stats, norm): x is the RAW block input and the LayerNorm is folded into the qkv GEMM (ops.linear_ln)."""
         s, t, c = x.shape
-        qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
+        if ln is not None:
+            stats, norm = ln
+            d = self.__dict__.setdefault("_ln_fold", Derived())
+            wg, cs, bp = d.get((self.qkv.weight, self.qkv.bias, norm.weight, norm.bias),
+                               lambda: ops.fold_ln_weights(self.qkv.weight, self.qkv.bias, norm.weight, norm.bias))
+            qkv = ops.linear_ln(x, stats, wg, cs, bp, norm.eps)
+        else:
+            qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
         a = ops.temporal_attention(qkv, s, t, c, self.heads, self.scale)
         return ops.linear(a, self.proj.weight, self.proj.bias, residual=residual), None
 
@@ -72,7 +80,17 @@ class Block(nn.Module):
             raise NotImplementedError("attention maps are not materialised")
         if self.training:
             refuse_stochastic_depth(self)
-        x, _ = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), mask, residual=x)
+        # norm1 folds into the qkv GEMM when the previous block's fc2 left row statistics on x (see SwinTransformerBlock.forward)
+        m, c = x.numel() // x.shape[-1], x.shape[-1]
+        st = ops.ln_stats_of(x)
+        if st is not None and ops.linear_ln_tiles(m, 3 * c, c) > 0:
+            x, _ = self.attn(x, mask, residual=x, ln=(st, self.norm1))
+        else:
+            x, _ = self.attn(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), mask, residual=x)
         if ops.storage() == "bf16" and isinstance(self.mlp, FeedForward):
             return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
+        emit = isinstance(self.mlp, FeedForward) and ops.linear_ln_tiles(m, c, self.mlp.fc1.out_features) > 0 and \
+            ops.linear_ln_tiles(m, 3 * c, c) > 0
+        if emit:
+            return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x, emit_stats=True)
         return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x)

@@ -70,9 +70,17 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
         self.drop = nn.Dropout(drop)
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, emit_stats=False):
         h = ops.linear(x, self.fc1.weight, self.fc1.bias, act=ops.ACT_GELU)
-        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=residual, emit_stats=emit_stats)
+
+    def forward_ln(self, x, stats, norm, emit_stats=False):
+        """x + fc2(GELU(fc1(LayerNorm(x)))) with the LayerNorm folded into fc1 (x raw, stats from x's producer)."""
+        d = self.__dict__.setdefault("_ln_fold", Derived())
+        wg, cs, bp = d.get((self.fc1.weight, self.fc1.bias, norm.weight, norm.bias),
+                           lambda: ops.fold_ln_weights(self.fc1.weight, self.fc1.bias, norm.weight, norm.bias))
+        h = ops.linear_ln(x, stats, wg, cs, bp, norm.eps, act=ops.ACT_GELU)
+        return ops.linear(h, self.fc2.weight, self.fc2.bias, residual=x, emit_stats=emit_stats)
 
     def forward_bf16(self, x16, residual):
         """bf16 storage (ops.set_storage("bf16")): x16 is the bf16 LayerNorm output, the 4C hidden tensor stays bf16, fc2
@@ -117,6 +125,15 @@ class WindowAttention(nn.Module):
             qkv = ops.linear_bf16s(x_normed, _w16(self, "qkv"), self.qkv.bias, out_bf16=True)
             return ops.window_attention_bf16(qkv, self.padded_bias(), b, hs, w, self.dim, shift, self.scale, tab, ids)
         qkv = ops.linear(x_normed, self.qkv.weight, self.qkv.bias)
+        return ops.window_attention(qkv, self.padded_bias(), b, hs, w, self.dim, shift, self.scale, tab, ids)
+
+    def attend_ln(self, x, stats, norm, b, hs, w, shift, mask):
+        """attend(LayerNorm(x)) with the LayerNorm folded into the qkv GEMM (x raw, stats from x's producer)."""
+        tab, ids = self.mask_pack(mask)
+        d = self.__dict__.setdefault("_ln_fold", Derived())
+        wg, cs, bp = d.get((self.qkv.weight, self.qkv.bias, norm.weight, norm.bias),
+                           lambda: ops.fold_ln_weights(self.qkv.weight, self.qkv.bias, norm.weight, norm.bias))
+        qkv = ops.linear_ln(x, stats, wg, cs, bp, norm.eps)
         return ops.window_attention(qkv, self.padded_bias(), b, hs, w, self.dim, shift, self.scale, tab, ids)
 
     def forward(self, x, mask=None):
@@ -164,10 +181,25 @@ class SwinTransformerBlock(nn.Module):
                                  self.shift_size, self.attn_mask)
             x = ops.linear_bf16s(a, _w16(self.attn, "proj"), self.attn.proj.bias, residual=x, out_bf16=False)
             return self.mlp.forward_bf16(ops.layernorm_bf16(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), x)
-        a = self.attn.attend(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs, w,
-                             self.shift_size, self.attn_mask)
-        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x)
-        return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x)
+        # LayerNorm folding (round 3): when the GEMM that produced x ran on the persistent kernel it left per-tile row statistics
+        # on x, and when the consuming GEMM runs there too it takes the RAW x and finishes the normalisation in its epilogue --
+        # no LayerNorm launch, no normalised copy of x (ops.linear_ln).  Anything else takes the two-launch route.
+        m = b * l
+        st = ops.ln_stats_of(x)
+        fold1 = st is not None and ops.linear_ln_tiles(m, 3 * c, c) > 0
+        fold2 = ops.linear_ln_tiles(m, c, c) > 0 and ops.linear_ln_tiles(m, self.mlp.fc1.out_features, c) > 0
+        if fold1:
+            a = self.attn.attend_ln(x, st, self.norm1, b, hs, w, self.shift_size, self.attn_mask)
+        else:
+            a = self.attn.attend(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), b, hs, w,
+                                 self.shift_size, self.attn_mask)
+        x = ops.linear(a, self.attn.proj.weight, self.attn.proj.bias, residual=x, emit_stats=fold2)
+        st = ops.ln_stats_of(x)
+        # (the block's output feeds the next block's norm1 -- or a patch merging, which ignores the statistics)
+        emit = ops.linear_ln_tiles(m, c, self.mlp.fc2.in_features) > 0 and ops.linear_ln_tiles(m, 3 * c, c) > 0
+        if st is not None:
+            return self.mlp.forward_ln(x, st, self.norm2, emit_stats=emit)
+        return self.mlp(ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=x, emit_stats=emit)
 
     def extra_repr(self):
         return (f"dim={self.dim}, input_resolution={self.input_resolution}, num_heads={self.num_heads}, "

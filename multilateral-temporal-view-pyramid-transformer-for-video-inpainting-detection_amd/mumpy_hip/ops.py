@@ -147,8 +147,10 @@ def layernorm(x, gamma, beta, eps=1e-5, out=None):
     return out
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
-    """y = act(x @ weight.T + bias) + residual; weight (N,K) or a 1x1-conv kernel (N,K,1,1)."""
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None, emit_stats=False):
+    """y = act(x @ weight.T + bias) + residual; weight (N,K) or a 1x1-conv kernel (N,K,1,1).
+    emit_stats: y feeds a LayerNorm whose consumer can fold it (linear_ln): when the shape runs on the persistent kernel the
+    epilogue also writes the per-tile row statistics, attached to the result as y._mumpy_ln_stats (else nothing happens)."""
     x = _chk(x, "x")
     weight = _chk(weight, "weight")
     n, k = weight.shape[0], weight.numel() // weight.shape[0]
@@ -165,10 +167,71 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None):
     wsb = _WS_BYTES.get(key)
     if wsb is None:
         wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
+    if emit_stats:
+        # measured (tools/ln_fold_shapes.py, profiles/r03_ln_fold_shapes.txt): the statistics epilogue costs 4-5 us on a producer with
+        # >= 16 chunks per tile (K >= 512) -- less than the LayerNorm launch it saves -- but 9-21 us on the short-K producers of
+        # stages 0 / 1 (K = 128, 256: their epilogue waves are the bottleneck already), more than the launch
+        gn = linear_ln_tiles(m, n, k) if k >= LN_FOLD_MIN_K else 0
+        if gn:
+            stats = torch.empty(m, gn, 2, device=x.device, dtype=torch.float32)
+            ws = _kept_workspace(max(wsb, 4096), x.device)
+            _call("mumpy_linear_lnx_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out), m, n, k,
+                  act, _p(ws), ws.numel() * 4, _p(stats), None, 0, None, 0.0, _stream(), work=2.0 * m * n * k)
+            out._mumpy_ln_stats = stats
+            return out
     ws = _kept_workspace(wsb, x.device) if wsb else None      # split-K slabs / the persistent kernel's flags + slabs
     _call("mumpy_linear_wsz_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
           _p(out), m, n, k, act | _MATH, _p(ws), 0 if ws is None else ws.numel() * 4, _stream(), work=2.0 * m * n * k)
     return out
+
+
+# ---- LayerNorm folded into the GEMMs either side of it (mumpy_linear_lnx_fwd; swin:266,305 / blocks:86-88) -----------------
+LN_FOLD = __import__("os").environ.get("MUMPY_LN_FOLD", "1") != "0"      # A/B switch
+LN_FOLD_MIN_K = 512
+_LN_TILES = {}
+
+
+def linear_ln_tiles(m, n, k):
+    """Column tiles of a shape whose fp32 launch runs on the persistent 128x128 kernel (the one that can emit / consume the
+    per-tile LayerNorm statistics), else 0.  0 as well whenever folding is off or another arithmetic mode is active."""
+    if not LN_FOLD or _MATH != MATH_FP32 or _STORAGE != "fp32":
+        return 0
+    key = (m, n, k)
+    t = _LN_TILES.get(key)
+    if t is None:
+        t = _LN_TILES[key] = int(_lib().mumpy_linear_ln_tiles(m, n, k))
+    return t
+
+
+def ln_stats_of(x):
+    """The per-tile row statistics the producing GEMM attached to x (linear(..., emit_stats=True)), or None."""
+    return getattr(x, "_mumpy_ln_stats", None)
+
+
+def linear_ln(x, stats, wg, colsum, bprime, eps, act=ACT_NONE):
+    """y = act(LayerNorm(x) W^T + b) with the LayerNorm folded into the GEMM: x RAW, stats from the producer of x, wg = W diag(gamma),
+    colsum = row sums of wg, bprime = W beta + b (see fold_ln_weights).  The caller checked linear_ln_tiles(m, n, k) > 0."""
+    x, wg = _chk(x, "x"), _chk(wg, "wg")
+    n, k = wg.shape
+    m = x.numel() // k
+    out = torch.empty(*x.shape[:-1], n, device=x.device, dtype=torch.float32)
+    wsb = _WS_BYTES.get((m, n, k))
+    if wsb is None:
+        wsb = _WS_BYTES[(m, n, k)] = int(_lib().mumpy_linear_workspace_bytes(m, n, k))
+    ws = _kept_workspace(max(wsb, 4096), x.device)
+    _call("mumpy_linear_lnx_fwd", _p(x), _p(wg), _p(_chk(bprime, "bprime")), None, _p(out), m, n, k, act, _p(ws), ws.numel() * 4, None,
+          _p(_chk(stats, "stats")), stats.shape[-2], _p(_chk(colsum, "colsum")), eps, _stream(), work=2.0 * m * n * k)
+    return out
+
+
+def fold_ln_weights(weight, bias, gamma, beta):
+    """(W diag(gamma), its row sums, W beta + b) in fp32, formed in float64: the operands of linear_ln."""
+    w64 = weight.detach().double()
+    wg = w64 * gamma.detach().double()[None, :]
+    bp = w64 @ beta.detach().double()
+    if bias is not None:
+        bp = bp + bias.detach().double()
+    return wg.float().contiguous(), wg.sum(1).float().contiguous(), bp.float().contiguous()
 
 
 _KEPT_WS = {}

@@ -292,6 +292,79 @@ def test_decoder_tail_fusion():
     assert float(cat[:, :256].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("m,c,n,gelu,shift", [(7840, 512, 1536, False, 0.0), (7840, 512, 2048, True, 0.0), (1960, 768, 2304, False, 0.0),
+                                              (31360, 256, 1024, True, 0.0), (125440, 128, 384, False, 0.0), (7840, 512, 1536, False, 30.0),
+                                              (7840, 512, 1536, False, 1000.0), (2000, 1024, 3072, False, 3.0)])
+def test_layernorm_folded_into_its_gemms(m, c, n, gelu, shift):
+    """y = act(LayerNorm(x) W^T + b) with the LayerNorm folded into the GEMMs either side of it (mumpy_linear_lnx_fwd; swin:266,305):
+    the producer x = h Wp^T + bp + r emits per-(row, 128-column tile) {mean, M2}, the consumer multiplies the RAW x by W diag(gamma)
+    and finishes rstd (acc - mean colsum) + (W beta + b) in its epilogue.  Checked against float64 LayerNorm + Linear of the x the
+    producer actually wrote, at the per-operator bar of the unfused path (5e-5 of the output scale), on the model's large shapes
+    (whole-tile and split schedules, GELU epilogue, ragged last row tile) -- and with rows whose mean is 30 / 1000 standard
+    deviations (shift): the in-tile two-pass + Chan combination keeps the variance, where a sum / sum-of-squares form would
+    cancel; there the bar is that of the two-launch path itself (its own error against float64, x 2)."""
+    kp = c if ops.linear_ln_tiles(m, c, c) > 0 else 4 * c                    # producer: the block's proj (K = C) or fc2 (K = 4C)
+    assert ops.linear_ln_tiles(m, c, kp) > 0 and ops.linear_ln_tiles(m, n, c) > 0, "shapes must run on the persistent kernel"
+    g = torch.Generator().manual_seed(m + n)
+    h = torch.randn(m, kp, generator=g)
+    wp, bp = torch.randn(c, kp, generator=g) / kp ** 0.5, torch.randn(c, generator=g)
+    r = torch.randn(m, c, generator=g) + shift
+    w, bias = torch.randn(n, c, generator=g) / c ** 0.5, torch.randn(n, generator=g)
+    gam, bet = 1.0 + 0.2 * torch.randn(c, generator=g), 0.2 * torch.randn(c, generator=g)
+    was = ops.LN_FOLD_MIN_K
+    ops.LN_FOLD_MIN_K = 0                                                    # (the planner's K >= 512 rule is a speed rule: test every shape)
+    try:
+        x = ops.linear(h.to(DEV), wp.to(DEV), bp.to(DEV), residual=r.to(DEV), emit_stats=True)
+    finally:
+        ops.LN_FOLD_MIN_K = was
+    st = ops.ln_stats_of(x)
+    gn = (c + 127) // 128
+    assert st is not None and st.shape == (m, gn, 2)
+    assert torch.equal(x, ops.linear(h.to(DEV), wp.to(DEV), bp.to(DEV), residual=r.to(DEV)))       # statistics change nothing in x
+    xd = x.cpu().double()
+    tiles = xd.reshape(m, gn, -1) if c % 128 == 0 else None
+    if tiles is not None:                                                    # the statistics themselves
+        assert rel_err(st[..., 0].cpu(), tiles.mean(-1)) < 1e-5
+        assert rel_err(st[..., 1].cpu(), ((tiles - tiles.mean(-1, keepdim=True)) ** 2).sum(-1)) < 1e-4
+    ref = F.layer_norm(xd, (c,), gam.double(), bet.double(), 1e-5) @ w.double().t() + bias.double()
+    if gelu:
+        ref = F.gelu(ref)
+    wg, cs, bpr = ops.fold_ln_weights(w.to(DEV), bias.to(DEV), gam.to(DEV), bet.to(DEV))
+    got = ops.linear_ln(x, st, wg, cs, bpr, 1e-5, act=ops.ACT_GELU if gelu else ops.ACT_NONE)
+    two = ops.linear(ops.layernorm(x, gam.to(DEV), bet.to(DEV)), w.to(DEV), bias.to(DEV), act=ops.ACT_GELU if gelu else ops.ACT_NONE)
+    e_fold, e_two = rel_err(got.cpu(), ref), rel_err(two.cpu(), ref)
+    assert e_fold < max(5e-5 if shift == 0.0 else 0.0, 2.0 * e_two + 1e-6), (e_fold, e_two)
+    assert torch.equal(got, ops.linear_ln(x, st, wg, cs, bpr, 1e-5, act=ops.ACT_GELU if gelu else ops.ACT_NONE))   # reproducible
+
+
+def test_layernorm_folding_is_what_the_blocks_run_and_can_be_switched_off():
+    """A stage-2 view-3 Swin block at the bench shape (M = 7840, C = 512): with folding on, the block's second LayerNorm and the next
+    block's first one launch no LayerNorm kernel (the count of mumpy_layernorm_fwd calls drops from 4 to 1 over two blocks), and the
+    result equals the two-launch route to fp32 rounding."""
+    from models.modules.swinTransformer import SwinTransformerBlock
+    blks = [fill_module_(SwinTransformerBlock(512, (14, 14), 16, window_size=7, shift_size=s, temporal_dim=5), f"lnf{s}/").eval().to(DEV)
+            for s in (0, 3)]
+    x = seeded_randn(77, 8, 5 * 196, 512).to(DEV)
+
+    def run():
+        ops.PROFILE = {}
+        with torch.no_grad():
+            y = blks[1](blks[0](x))
+        torch.cuda.synchronize()
+        prof, ops.PROFILE = ops.PROFILE, None
+        return y, len(prof.get("mumpy_layernorm_fwd", [])), len(prof.get("mumpy_linear_lnx_fwd", []))
+    was = ops.LN_FOLD
+    try:
+        ops.LN_FOLD = True
+        y1, n_ln1, n_lnx1 = run()
+        ops.LN_FOLD = False
+        y0, n_ln0, n_lnx0 = run()
+    finally:
+        ops.LN_FOLD = was
+    assert (n_ln0, n_lnx0) == (4, 0) and (n_ln1, n_lnx1) == (1, 7), (n_ln0, n_lnx0, n_ln1, n_lnx1)
+    assert rel_err(y1.cpu(), y0.cpu()) < 2e-5
+
+
 @pytest.mark.parametrize("c,side,r", [(96, 14, 5), (96, 14, 1), (192, 14, 3), (384, 7, 5), (768, 7, 5), (768, 7, 1)])
 def test_deform_fused_gemms_match_the_unfused_kernels(c, side, r):
     """csrc/cva_fused.hip against the launch sequences they replace, on the encoder's four widths, ragged tile edges (98 / 392 /
