@@ -431,6 +431,7 @@ def main():
     metric = D.all_reduce_metric(D.eval_metric_vector(mask, gt))
     barrier()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev if backend == "nccl" else None)
+    ops.check_workspaces()          # (outside the timed region) no split GEMM launch gave up on a partial tile: the masks are complete
 
     if rank == 0:
         log(f"timed: {1e3 * dt / args.steps:.2f} ms/step; profiling kernels")

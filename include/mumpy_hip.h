@@ -52,6 +52,18 @@ extern "C" {
 
 int         mumpy_abi_version(void);
 const char* mumpy_last_error(void);
+/* 1: diagnostics build (`make TUNING=1`): planner / kernel A/B hooks read MUMPY_* environment variables.  0: the shipped library,
+ * which reads no environment variable and keeps no mutable global state besides the thread-local error string and the cached
+ * compute-unit count of the first device used. */
+int         mumpy_tuning_build(void);
+
+/* Sticky status word of a workspace kept for mumpy_linear_wsz_fwd / mumpy_linear_lnx_fwd (the one call of this library that
+ * synchronises: it copies the word back).  *status = 0: fine; b + 1: a split ("stream-K") launch gave up waiting for workgroup b's
+ * part -- its output is incomplete; discard it and re-zero the workspace's first 4096 bytes before the next launch;
+ * -1: a LayerNorm-folding consumer (mumpy_linear_lnx_fwd) met a row whose |mean| exceeds 256 standard deviations: results are
+ * complete but that row carries ~1e-4 relative error instead of ~1e-6 (the product is taken on the un-centred x) -- take the
+ * two-launch route (mumpy_layernorm_fwd + mumpy_linear_wsz_fwd) for such data; the word is sticky until re-zeroed. */
+int mumpy_workspace_status(const void* workspace, int* status);
 
 /* ---- LayerNorm folded into the GEMMs either side of it (round 3; swin:266,305: x + f(norm(x)) chains) ----
  * A pre-norm block computes  y = act(LayerNorm(x) W^T + b)  right after a residual GEMM produced x.  Instead of a LayerNorm

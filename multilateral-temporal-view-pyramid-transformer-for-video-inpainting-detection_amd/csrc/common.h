@@ -17,6 +17,16 @@ constexpr int HD = 32;       // head width of every Swin / deformable head
 
 void set_error(const char* fmt, ...);
 
+// Tuning hooks.  The shipped library reads NO environment variables: tune_int() is the constant default.  A diagnostics build
+// (make TUNING=1 -> -DMUMPY_TUNING) reads MUMPY_* variables once per process for A/B runs (tools/gemm_shapes.py & co).
+#ifdef MUMPY_TUNING
+int tune_int(const char* name, int dflt);
+const char* tune_str(const char* name);
+#else
+inline int tune_int(const char*, int dflt) { return dflt; }
+inline const char* tune_str(const char*) { return nullptr; }
+#endif
+
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

@@ -280,7 +280,7 @@ extern "C" int mumpy_deform_sample_fwd(const float* x2, const float* pos, float*
     const int nWx = W / WS, nW2 = (Hs2 / WS) * nWx;
     const int64_t nwin = (int64_t)B * nW2;
     MUMPY_REQUIRE(nwin < (1ll << 31), MUMPY_ERANGE, "deform_sample: too many windows");
-    static const bool direct = getenv("MUMPY_SAMPLE_DIRECT") && atoi(getenv("MUMPY_SAMPLE_DIRECT")) != 0;   // A/B hook
+    static const bool direct = tune_int("MUMPY_SAMPLE_DIRECT", 0) != 0;   // A/B hook
 #define MUMPY_SAMPLE(C_)                                                                                             \
     if (direct)                                                                                                      \
         hipLaunchKernelGGL(deform_sample_kernel<C_>, dim3((unsigned)nwin), dim3(256), 0, as_stream(stream), x2, pos, out,  \

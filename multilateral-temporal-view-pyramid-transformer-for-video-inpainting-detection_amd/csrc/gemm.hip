@@ -679,7 +679,7 @@ Plan make_plan_x3(int64_t M, int N, int K, bool allow_split) {
 }
 
 Plan make_plan(int64_t M, int N, int K, bool allow_split, bool x3 = false) {
-    static const char* force = getenv("MUMPY_GEMM_FORCE");      // tuning hook: "tile,ksplit"
+    static const char* force = tune_str("MUMPY_GEMM_FORCE");      // tuning hook: "tile,ksplit"
     if (x3 && !force) return make_plan_x3(M, N, K, allow_split);
     Plan p;
     const int64_t gm128 = (M + 127) / 128, gm64 = (M + 63) / 64;
@@ -734,7 +734,7 @@ int device_cus() {
 // and cuts a tile into <= 3 parts; leave the deep-K shapes with two or more tiles per CU to the tiled kernels (two co-resident
 // workgroups hide each other's prologue and epilogue there: 121 TFLOP/s).
 int ws_plan(int64_t M, int N, int K, bool have_ws, bool conv) {
-    static const int ws_mode = getenv("MUMPY_GEMM_WS") ? atoi(getenv("MUMPY_GEMM_WS")) : 2;
+    static const int ws_mode = tune_int("MUMPY_GEMM_WS", 2);
     const int num_cu = device_cus();
     const int64_t tiles = ((M + 127) / 128) * ((N + 127) / 128);
     const int nk = K / 32;
@@ -786,7 +786,7 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
         // wins up to 32 chunks deep when the tiles fill at most one round of the 2 x CUs slots or at least 2.5, and for the
         // short-K shapes (<= 12 chunks) in between; deeper K wants the tiled kernels' split-K, a GELU epilogue is bound by the
         // epilogue waves (two matrix waves per SIMD leave them even fewer issue slots).  =0 disables it, =2 forces it.
-        static const int ws64_mode = getenv("MUMPY_GEMM_WS64") ? atoi(getenv("MUMPY_GEMM_WS64")) : 1;
+        static const int ws64_mode = tune_int("MUMPY_GEMM_WS64", 1);
         if (!how && !conv && ws64_mode) {
             const int64_t t64 = ((M + 63) / 64) * ((N + 63) / 64);
             const double r64 = (double)t64 / (2.0 * num_cu);
@@ -820,7 +820,7 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
     hipLaunchKernelGGL((linear_kernel<BM_, BN_, WM_, WN_, CV_, false>), dim3((unsigned)grid),                        \
                        dim3(64 * (BM_ / WM_) * (BN_ / WN_)), 0, s, x, W, bias, residual, y, M, N, K, act, p.gn, p.ksplit, \
                        ws, rpb, bstride, cg)
-    static const bool use_glds = getenv("MUMPY_GEMM_GLDS") ? atoi(getenv("MUMPY_GEMM_GLDS")) != 0 : false;
+    static const bool use_glds = tune_int("MUMPY_GEMM_GLDS", 0) != 0;
     if (math_x3) {
         const bool wide = (p.tile == 0 || p.tile == 3);
 #define MUMPY_GEMM_X3(BM_, BN_, WM_, WN_, CV_, NB_)                                                                    \
@@ -951,7 +951,7 @@ extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float*
     // the tiled kernel's load -> convert -> LDS loop everywhere (forward of config 3: 725 -> 797 clips/s against taking it
     // only for >= 0.75 of a round of tiles).  MUMPY_GEMM_WS16=0 disables it, =1 restricts it to the large shapes (A/B runs).
     {
-        static const int ws16 = getenv("MUMPY_GEMM_WS16") ? atoi(getenv("MUMPY_GEMM_WS16")) : 2;
+        static const int ws16 = tune_int("MUMPY_GEMM_WS16", 2);
         static int num_cu = 0;
         if (!num_cu) {
             int dev = 0;
@@ -998,6 +998,19 @@ extern "C" int mumpy_linear_wsz_fwd(const float* x, const float* W, const float*
     MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "linear: workspace must be 16-byte aligned");
     return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream), 0, 0, nullptr, true);
+}
+
+// Sticky status of a kept workspace (blocking: copies one word back).  0 = fine; b + 1 = the owner of a split tile gave up waiting
+// for the part of workgroup b (gemm_ws.h) -- the launch's output is incomplete and the flag page may hold a stale arrival: the
+// caller must discard the results and re-zero the workspace before using it again.
+extern "C" int mumpy_workspace_status(const void* workspace, int* status) {
+    MUMPY_REQUIRE(workspace && status, MUMPY_ENULL, "workspace_status: null pointer");
+    unsigned w[2] = {0, 0};                                  // [LN_GUARD_WORD, STATUS_WORD] are neighbours
+    static_assert(gemm_ws::LN_GUARD_WORD + 1 == gemm_ws::STATUS_WORD, "status words must be adjacent");
+    hipError_t e = hipMemcpy(w, static_cast<const unsigned*>(workspace) + gemm_ws::LN_GUARD_WORD, sizeof(w), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { set_error("workspace_status: %s", hipGetErrorString(e)); return (int)e; }
+    *status = w[1] ? (int)w[1] : (w[0] ? -1 : 0);
+    return 0;
 }
 
 // ---- LayerNorm folded into the GEMMs either side of it (gemm_ws.h, epilogue_role<.., LN>) ------------------------------------

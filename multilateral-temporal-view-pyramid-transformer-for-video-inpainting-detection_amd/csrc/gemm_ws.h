@@ -52,6 +52,9 @@ constexpr int PASSES = BM / 8;              // epilogue passes per tile: 8 rows 
 #endif
 constexpr int DBG = MUMPY_WS_DBG;
 constexpr uint32_t OOB = 0x80000000u;       // buffer offset past every buffer: the access is dropped by the bounds check
+constexpr int LN_GUARD_WORD = 1022;         // sticky: a folded LayerNorm met a row with |mean| > LN_GUARD_RATIO sigma (reduced accuracy)
+constexpr float LN_GUARD_RATIO = 256.f;
+constexpr int STATUS_WORD = 1023;           // last word of the flag page: sticky "a split part never arrived" status (0 = fine)
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -85,6 +88,7 @@ struct Params {
     const float* ln_colsum;  // LN = 2: [N] sum_k W[n][k] gamma[k]
     int ln_gn, ln_C;
     float ln_eps;
+    unsigned* ln_guard;    // LN = 2: sticky precision-guard word of the workspace's flag page, or null
 #ifdef MUMPY_WS_STAMP
     unsigned long long* stamps;   // diagnostics build: [block][8] cycle sums
 #endif
@@ -533,6 +537,11 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
             }
             ln_mean = mean;
             ln_rstd = rsqrtf(m2 / (float)p.ln_C + p.ln_eps);
+            // precision guard: the product is taken on the UN-centred x, so acc - mean colsum loses ~log2(|mean| / sigma) bits
+            // (measured: 1.2e-5 of the output scale at |mean| = 30 sigma against 1e-6 for the two-launch route).  Rows beyond
+            // 256 sigma (> 1e-4) raise a sticky word of the workspace; ops.check_workspaces() reports it and turns folding off.
+            if (fabsf(mean) * ln_rstd > LN_GUARD_RATIO && row < (uint32_t)p.M && p.ln_guard)
+                __hip_atomic_store(p.ln_guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     };
     auto pass = [&](int e) {                        // e is a compile-time constant at every call site
@@ -653,6 +662,13 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
                 unsigned spins = 0;
                 while (__hip_atomic_load(p.flags + b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u && ++spins < (1u << 24))
                     __builtin_amdgcn_s_sleep(8);
+                if (spins >= (1u << 24)) {
+                    // the part never arrived (cannot happen while every workgroup of the launch runs: a first segment depends on
+                    // nothing).  Do not pretend: raise the STICKY status word of the workspace (the host turns it into an error,
+                    // mumpy_workspace_status) and leave the flag alone -- a late arrival must not be mistaken for the next launch's.
+                    __hip_atomic_store(p.flags + STATUS_WORD, 1u + b2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    continue;
+                }
                 __hip_atomic_store(p.flags + b2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -758,6 +774,7 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     p.ln_stats = ln ? ln->ln_stats : nullptr;
     p.ln_colsum = ln ? ln->ln_colsum : nullptr;
     p.ln_gn = ln ? ln->ln_gn : 0; p.ln_C = ln ? ln->ln_C : 0; p.ln_eps = ln ? ln->ln_eps : 0.f;
+    p.ln_guard = (ln && ln->ln_stats && ws && ws_bytes >= 4096) ? static_cast<unsigned*>(ws) + LN_GUARD_WORD : nullptr;
     const int ln_mode = !ln ? 0 : (ln->stats_out ? 1 : 2);
     p.cv_H = p.cv_W = p.cv_C = p.cv_kh = p.cv_kw = p.cv_cpc = 0;
     p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
@@ -859,7 +876,7 @@ inline int launch16(const void* x16, const void* W16, const float* bias, const f
     p.cv_mhw = p.cv_shw = p.cv_mw = p.cv_sw = 0;
     p.X = static_cast<const float*>(x16); p.W = static_cast<const float*>(W16); p.bias = bias; p.residual = residual;
     p.Y = static_cast<float*>(y);
-    p.stats_out = nullptr; p.ln_stats = nullptr; p.ln_colsum = nullptr; p.ln_gn = p.ln_C = 0; p.ln_eps = 0.f;
+    p.stats_out = nullptr; p.ln_stats = nullptr; p.ln_colsum = nullptr; p.ln_gn = p.ln_C = 0; p.ln_eps = 0.f; p.ln_guard = nullptr;
     p.M = (int)M; p.N = N; p.K = K; p.act = act; p.nk = K / 64;
     p.gm = (unsigned)((M + BM - 1) / BM); p.gn = (unsigned)((N + BN - 1) / BN);
     p.tiles = p.gm * p.gn;

@@ -935,13 +935,13 @@ static int window_attention_launch(bool io16, const float* qkv, float* out, cons
     a.qkv = qkv; a.out = out; a.bias = bias; a.mask_tab = mask_tab; a.mask_id = mask_id;
     a.B = B; a.Hs = Hs; a.W = W; a.C = C; a.nH = C / HD; a.shift = shift;
     a.nWx = W / WS; a.nW = (Hs / WS) * (W / WS); a.scale = scale; a.n_mask = n_mask > 0 ? n_mask : 1;
-    static const int dbgmask = getenv("MUMPY_WA_DBG") ? atoi(getenv("MUMPY_WA_DBG")) : 0;
+    static const int dbgmask = tune_int("MUMPY_WA_DBG", 0);
     a.dbg = dbgmask;
     a.units = (int64_t)B * a.nW * a.nH;
     // persistent grid: ~3 resident blocks per CU (3 waves/SIMD); each block walks its head's window quads
     const int64_t quads = ((int64_t)B * a.nW + 3) / 4;
-    static const int wa_blocks = getenv("MUMPY_WA_BLOCKS") ? atoi(getenv("MUMPY_WA_BLOCKS")) : 768;
-    static const int wa_stagger = getenv("MUMPY_WA_STAGGER") ? atoi(getenv("MUMPY_WA_STAGGER")) : 0;
+    static const int wa_blocks = tune_int("MUMPY_WA_BLOCKS", 768);
+    static const int wa_stagger = tune_int("MUMPY_WA_STAGGER", 0);
     int64_t groups = (wa_blocks + a.nH - 1) / a.nH;
     if (groups > quads) groups = quads;
     a.groups = (int)groups; a.stagger = wa_stagger;

@@ -23,6 +23,8 @@ SIGNATURES = {
     "mumpy_linear_ws_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_linear_wsz_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_linear_workspace_bytes": [c_l, c_i, c_i],
+    "mumpy_tuning_build": [],
+    "mumpy_workspace_status": [c_f, ctypes.POINTER(ctypes.c_int)],
     "mumpy_linear_ln_tiles": [c_l, c_i, c_i],
     "mumpy_linear_lnx_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f, c_f, c_i, c_f, c_fl, c_f],
     "mumpy_linear_rows_fwd": [c_f, c_l, c_l, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
@@ -87,12 +89,23 @@ ABI_VERSION = 2
 
 
 def library_path() -> str:
-    return os.environ.get("MUMPY_HIP_LIB", os.path.join(_PKG, "lib", "libmumpy_hip.so"))
+    """MUMPY_HIP_LIB=<file> overrides; MUMPY_TUNING=1 selects the diagnostics build (tools/gemm_shapes.py & co: the only build
+    whose kernels' A/B hooks read MUMPY_GEMM_* / MUMPY_WA_* variables).  This choice is the binding's, not the library's."""
+    if "MUMPY_HIP_LIB" in os.environ:
+        return os.environ["MUMPY_HIP_LIB"]
+    name = "libmumpy_hip_tuning.so" if os.environ.get("MUMPY_TUNING", "0") == "1" else "libmumpy_hip.so"
+    return os.path.join(_PKG, "lib", name)
+
+
+def tuning_library_path() -> str:
+    """The diagnostics build (same sources, -DMUMPY_TUNING): its planner / kernel A/B hooks read MUMPY_* environment variables.
+    Select it for a process with MUMPY_HIP_LIB=<this path>; the shipped library reads no environment variable."""
+    return os.path.join(_PKG, "lib", "libmumpy_hip_tuning.so")
 
 
 def build_library(verbose: bool = False) -> str:
     """Compile every HIP source for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    r = subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-j8"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", os.path.join(_PKG, "csrc"), "-j8", "all", "tuning"], capture_output=True, text=True)
     if verbose or r.returncode:
         print(r.stdout[-4000:], r.stderr[-4000:])
     if r.returncode:

@@ -99,3 +99,18 @@ def test_resize_nearest_table_is_pillows(src, dst):
     ramp = np.arange(src, dtype=np.int32).reshape(1, src)                     # mode "I": pixel value = source column
     pil = np.array(Image.fromarray(ramp, mode="I").resize((dst, 1), Image.NEAREST)).reshape(-1)
     assert list(tab) == pil.tolist()
+
+
+def test_shipped_library_reads_no_environment_and_the_tuning_build_exists():
+    """The shipped libmumpy_hip.so is built without the tuning hooks (mumpy_tuning_build() == 0: no getenv in the library, the
+    planner is a pure function of the shape); the diagnostics build that tools/ and the variant tests select with MUMPY_HIP_LIB is
+    a separate file with the same exported symbols."""
+    import os
+    import subprocess
+    from mumpy_hip.lib import library_path, load_library, tuning_library_path
+    assert load_library().mumpy_tuning_build() == 0
+    nm = subprocess.run(["nm", "-D", "--undefined-only", library_path()], capture_output=True, text=True).stdout
+    assert "getenv" not in nm
+    assert os.path.exists(tuning_library_path()), "run `python __graft_entry__.py` (builds both libraries)"
+    t = ctypes.CDLL(tuning_library_path())
+    assert t.mumpy_tuning_build() == 1 and t.mumpy_abi_version() == load_library().mumpy_abi_version()
