@@ -48,10 +48,27 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
         }                                                                            \
     } while (0)
 
+// Cross-lane all-reduce building blocks.  A butterfly from the low bit up: after the steps for 1 and 2 every lane of a quad
+// holds the quad's sum, so the "xor 4" / "xor 8" partners can be ANY lane of the other quad / other half-row -- DPP's
+// row_half_mirror and row_mirror, which (like the quad permutes) fold into the v_add itself: one VALU instruction per step
+// instead of an address computation + ds_bpermute round trip (~100 cycles) per step.  xor 16 stays inside 32 lanes: ds_swizzle
+// (bit-mask mode, no address register); only xor 32 needs the permute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float swz_xor16(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), (16 << 10) | 0x1f));
+}
+
+// sum over aligned groups of `width` lanes (a power of two <= 64), result in every lane of the group; all lanes active
 __device__ __forceinline__ float wave_sum(float v, int width) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1)
-        if (o < width) v += __shfl_xor(v, o);
+    if (width > 1) v += dpp_f<0xB1>(v);        // quad_perm [1,0,3,2]
+    if (width > 2) v += dpp_f<0x4E>(v);        // quad_perm [2,3,0,1]
+    if (width > 4) v += dpp_f<0x141>(v);       // row_half_mirror
+    if (width > 8) v += dpp_f<0x140>(v);       // row_mirror
+    if (width > 16) v += swz_xor16(v);
+    if (width > 32) v += __shfl_xor(v, 32);
     return v;
 }
 

@@ -403,6 +403,29 @@ __global__ __launch_bounds__(256) void xgemm_reduce_kernel(const f32x4* __restri
     reduce_rowsum(rs, ks);
 }
 
+// two reductions in ONE launch (the dX and the dW product of a Linear backward, both split): blocks [0, g0) take job 0, the rest
+// job 1; each job is the fixed-order sum above.  Saves a launch per nn.Linear of the training step (~250 of them).
+struct ReduceJob { const f32x4* slabs; f32x4* out; int64_t n4; int ks, accum; unsigned blocks; };
+__global__ __launch_bounds__(256) void xgemm_reduce2_kernel(ReduceJob j0, ReduceJob j1, RowSumArgs rs) {
+    const bool second = blockIdx.x >= j0.blocks;
+    const ReduceJob& j = second ? j1 : j0;
+    const unsigned bid = second ? blockIdx.x - j0.blocks : blockIdx.x;
+    for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < j.n4; i += (int64_t)j.blocks * 256) {
+        f32x4 s = j.slabs[i];
+        for (int z = 1; z < j.ks; ++z) s += j.slabs[(int64_t)z * j.n4 + i];
+        if (j.accum) s += j.out[i];
+        j.out[i] = s;
+    }
+    if (second) {                                   // the bias-gradient partials ride with the dW job
+        if (!rs.out) return;
+        for (int i = bid * 256 + threadIdx.x; i < rs.R; i += j1.blocks * 256) {
+            float s = rs.slabs[i];
+            for (int z = 1; z < j1.ks; ++z) s += rs.slabs[(int64_t)z * rs.R + i];
+            rs.out[i] = rs.accum ? rs.out[i] + s : s;
+        }
+    }
+}
+
 // the same for the convolution gradient: slabs [split][tap][R][C] -> out[r][tap * C + c] (row pitch ldo = taps * C)
 __global__ __launch_bounds__(256) void xgemm_reduce_taps_kernel(const f32x4* __restrict__ slabs, float* __restrict__ out, int R, int C,
                                                                 int taps, int ks, int accum, RowSumArgs rs) {
@@ -500,8 +523,11 @@ int64_t colsum_blocks(int64_t R) {
 
 // rowsum (A_T only): also write / accumulate the row sums of A over the contraction (the bias gradient) -- the slab layout
 // is [ks][R][C] followed by [ks][R] row-sum partials
+// defer: when non-null and the product is split, the reduce is NOT launched; its description is returned for xgemm_reduce2_kernel
+struct Deferred { ReduceJob job; RowSumArgs rs; bool pending; };
 int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t ldb, float* out, int64_t ldo, int R, int C, int KK,
-                 int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0, bool bf16 = false) {
+                 int accum, float* ws, int64_t ws_bytes, hipStream_t s, float* rowsum = nullptr, int rowsum_accum = 0, bool bf16 = false,
+                 Deferred* defer = nullptr) {
     XPlan p = plan(R, C, KK);
     if (p.ks > 1 && (ldo != C || (int64_t)p.ks * R * (C + (rowsum ? 1 : 0)) * 4 > ws_bytes)) { p.ks = 1; p.cps = p.nchunks; }
     XArgs a;
@@ -526,15 +552,28 @@ int launch_xgemm(bool a_t, const float* A, int64_t lda, const float* B, int64_t 
         else hipLaunchKernelGGL((xgemm_kernel<32, false>), grid, dim3(256), 0, s, a);
     }
     MUMPY_CHECK_LAUNCH("linear_bwd(product)");
+    if (defer) defer->pending = false;
     if (p.ks > 1) {
         const int64_t n4 = (int64_t)R * C / 4;
         int64_t g = (n4 + 255) / 256;
         if (g > 2048) g = 2048;
         const RowSumArgs rs{a.rowsum_slabs, rowsum, R, rowsum_accum};
+        if (defer) {
+            defer->job = ReduceJob{reinterpret_cast<const f32x4*>(ws), reinterpret_cast<f32x4*>(out), n4, p.ks, accum, (unsigned)g};
+            defer->rs = rs;
+            defer->pending = true;
+            return 0;
+        }
         hipLaunchKernelGGL(xgemm_reduce_kernel, dim3((unsigned)g), dim3(256), 0, s, reinterpret_cast<const f32x4*>(ws),
                            reinterpret_cast<f32x4*>(out), n4, p.ks, accum, rs);
         MUMPY_CHECK_LAUNCH("linear_bwd(reduce)");
     }
+    return 0;
+}
+
+int launch_reduce(const Deferred& d, hipStream_t s) {
+    hipLaunchKernelGGL(xgemm_reduce_kernel, dim3(d.job.blocks), dim3(256), 0, s, d.job.slabs, d.job.out, d.job.n4, d.job.ks, d.job.accum, d.rs);
+    MUMPY_CHECK_LAUNCH("linear_bwd(reduce)");
     return 0;
 }
 
@@ -546,7 +585,8 @@ extern "C" int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K) {
     int64_t need = p.ks > 1 ? (int64_t)p.ks * N * (K + 1) * 4 : 0;          // dW slabs + the bias-gradient partials
     const XPlan q = plan((int)M, K, N);
     const int64_t dx_slabs = q.ks > 1 ? (int64_t)q.ks * M * K * 4 : 0;      // dX slabs (deep N, few tiles); skipped when huge
-    if (dx_slabs <= (256ll << 20) && dx_slabs > need) need = dx_slabs;
+    if (dx_slabs <= (256ll << 20)) need += dx_slabs;                         // BEHIND the dW slabs: both products' slabs are alive
+                                                                             // until the one reduce launch that sums them
     const int64_t cs = colsum_blocks(M) * N * 4;
     return need > cs ? need : cs;
 }
@@ -581,11 +621,25 @@ extern "C" int mumpy_linear_bwd(const float* x, const float* W, const float* dy,
         hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((N + 63) / 64)), dim3(256), 0, s, ws, db, (int)nb, N, (accumulate >> 1) & 1);
         MUMPY_CHECK_LAUNCH("linear_bwd(bias)");
     }
+    // workspace layout: [dW slabs + bias-gradient partials | dX slabs]; when both products are split their reduces are ONE launch
+    const XPlan pw = plan(N, K, (int)M);
+    const int64_t w_bytes = (dW && pw.ks > 1) ? (int64_t)pw.ks * N * (K + 1) * 4 : 0;
+    float* ws_x = ws ? ws + w_bytes / 4 : nullptr;
+    const int64_t ws_x_bytes = workspace ? workspace_bytes - w_bytes : 0;
+    Deferred dfx{}, dfw{};
     if (dx)          // dX[M,K] = dY[M,N] W[N,K]
-        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws, workspace ? workspace_bytes : 0, s, nullptr, 0, bf16)) return rc;
+        if (int rc = launch_xgemm(false, dy, N, W, K, dx, K, (int)M, K, N, 0, ws_x, ws_x_bytes > 0 ? ws_x_bytes : 0, s, nullptr, 0, bf16,
+                                  dW ? &dfx : nullptr)) return rc;
     if (dW)          // dW[N,K] (+)= dY^T X
         if (int rc = launch_xgemm(true, dy, N, x, K, dW, K, N, K, (int)M, accumulate & 1, ws, workspace ? workspace_bytes : 0, s, db,
-                                  (accumulate >> 1) & 1, bf16)) return rc;
+                                  (accumulate >> 1) & 1, bf16, dx ? &dfw : nullptr)) return rc;
+    if (dfx.pending && dfw.pending) {
+        hipLaunchKernelGGL(xgemm_reduce2_kernel, dim3(dfx.job.blocks + dfw.job.blocks), dim3(256), 0, s, dfx.job, dfw.job, dfw.rs);
+        MUMPY_CHECK_LAUNCH("linear_bwd(reduce x2)");
+    } else {
+        if (dfx.pending) if (int rc = launch_reduce(dfx, s)) return rc;
+        if (dfw.pending) if (int rc = launch_reduce(dfw, s)) return rc;
+    }
     return 0;
 }
 

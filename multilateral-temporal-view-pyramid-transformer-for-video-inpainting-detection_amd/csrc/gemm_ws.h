@@ -456,18 +456,9 @@ __device__ __forceinline__ void loader_role(const Params& p, float* lds, unsigne
 // GELU pass, which fit the issue slots the MFMA stream leaves.  The pass code is unrolled with static register indices;
 // the chunks that remain of a tile only join the barrier.
 // OUT16: y is bf16 (config 3's activation storage; no residual then): a pass packs its four values and stores 8 bytes.
-// sum over the 32 lanes of this lane's half-wave (the lanes that share an epilogue row), result in all of them; ds_swizzle in
-// bit-mask mode (xor masks stay inside groups of 32): one LDS-crossbar instruction per step, no address arithmetic
-__device__ __forceinline__ float half_sum32(float x) {
-#define MUMPY_SWZ_XOR(k_) __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), ((k_) << 10) | 0x1f))
-    x += MUMPY_SWZ_XOR(1);
-    x += MUMPY_SWZ_XOR(2);
-    x += MUMPY_SWZ_XOR(4);
-    x += MUMPY_SWZ_XOR(8);
-    x += MUMPY_SWZ_XOR(16);
-#undef MUMPY_SWZ_XOR
-    return x;
-}
+// sum over the 32 lanes of this lane's half-wave (the lanes that share an epilogue row), result in all of them: four DPP adds and
+// one ds_swizzle (common.h)
+__device__ __forceinline__ float half_sum32(float x) { return wave_sum(x, 32); }
 
 template <int P, bool OUT16 = false, int LN = 0>
 __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsigned b, unsigned G, unsigned u0, unsigned u1, int hl) {

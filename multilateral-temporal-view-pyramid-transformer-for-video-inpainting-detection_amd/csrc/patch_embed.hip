@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                           float eps) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int lda = K + 1;          // odd stride: conflict-free column reads
-    const int ldo = C + 1;
+    const int ldo = C + 4;          // output tile pitch: 16-byte aligned rows; 16 tokens x 4 lanes of the statistics pass hit 64 banks
     float* As = sm;                 // [64][K+1]; reused as the output tile [64][C+1]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane & 31, h = lane >> 5;
@@ -93,18 +93,34 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
             for (int r = 0; r < 16; ++r) As[(32 * i + (r & 3) + 8 * (r >> 2) + 4 * h) * ldo + n] = acc[i][r] + bv;
     }
     __syncthreads();
-    // LayerNorm per token: 16 tokens per wave, lanes over channels (C <= 128: two per lane)
-    for (int ml = wave; ml < TM; ml += 4) {
+    // LayerNorm per token.  Statistics: FOUR lanes per token (lane qd walks channels qd, qd + 4, ...), partial sums combined with two
+    // quad shuffles; then a coalesced normalise-and-store pass, four channels per lane.  (The first version gave a wave to a token
+    // and reduced across its 64 lanes twice per token -- 16 tokens x 12 cross-lane steps per wave were most of the kernel's time.)
+    float* st = sm + TM * ldo;      // [64][2]: mean, rstd (behind the output tile)
+    {
+        const int ml = tid >> 2, qd = tid & 3;
+        const float* row = As + ml * ldo;
+        float s = 0.f;
+        for (int ch = qd; ch < C; ch += 4) s += row[ch];
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int ch = qd; ch < C; ch += 4) { const float d = row[ch] - mean; q = fmaf(d, d, q); }
+        q += __shfl_xor(q, 1);
+        q += __shfl_xor(q, 2);
+        if (qd == 0) { st[2 * ml] = mean; st[2 * ml + 1] = rsqrtf(q / (float)C + eps); }
+    }
+    __syncthreads();
+    const int c4n = C >> 2;
+    for (int idx = tid; idx < TM * c4n; idx += 256) {
+        const int ml = idx / c4n, c4 = idx - ml * c4n;
         const int64_t m = m0 + ml;
         if (m >= Mtot) break;
-        const float v0 = (lane < C) ? As[ml * ldo + lane] : 0.f;
-        const float v1 = (lane + 64 < C) ? As[ml * ldo + lane + 64] : 0.f;
-        const float mean = wave_sum(v0 + v1, 64) / (float)C;
-        const float d0 = (lane < C) ? v0 - mean : 0.f, d1 = (lane + 64 < C) ? v1 - mean : 0.f;
-        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1, 64) / (float)C + eps);
-        float* o = out + m * C;
-        if (lane < C) o[lane] = d0 * rstd * gamma[lane] + beta[lane];
-        if (lane + 64 < C) o[lane + 64] = d1 * rstd * gamma[lane + 64] + beta[lane + 64];
+        const f32x4 v = *reinterpret_cast<const f32x4*>(As + ml * ldo + 4 * c4);
+        const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * c4), b4 = *reinterpret_cast<const f32x4*>(beta + 4 * c4);
+        const float mean = st[2 * ml], rstd = st[2 * ml + 1];
+        *reinterpret_cast<f32x4*>(out + m * C + 4 * c4) = (v - mean) * rstd * g4 + b4;
     }
 }
 
@@ -114,7 +130,8 @@ extern "C" int mumpy_patch_embed_fwd(const float* x, const float* Wt, const floa
                                      const float* beta, float* out, int B, int T, int H, int W, int t, int C, float eps,
                                      void* stream) {
     MUMPY_REQUIRE(x && Wt && bias && gamma && beta && out, MUMPY_ENULL, "patch_embed: null pointer");
-    MUMPY_REQUIRE(aligned16(x), MUMPY_EALIGN, "patch_embed: x must be 16-byte aligned");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(out) && aligned16(gamma) && aligned16(beta), MUMPY_EALIGN,
+                  "patch_embed: x, out, gamma and beta must be 16-byte aligned");
     MUMPY_REQUIRE(B > 0 && T > 0 && t > 0 && t <= T && H % 4 == 0 && W % 4 == 0, MUMPY_EINVAL,
                   "patch_embed: bad clip shape T=%d t=%d H=%d W=%d", T, t, H, W);
     MUMPY_REQUIRE(C % 32 == 0 && C >= 32 && C <= 128, MUMPY_ERANGE, "patch_embed: C=%d must be 32..128, multiple of 32", C);
@@ -122,8 +139,8 @@ extern "C" int mumpy_patch_embed_fwd(const float* x, const float* Wt, const floa
     MUMPY_REQUIRE(K <= 1024, MUMPY_ERANGE, "patch_embed: tubelet %d too long", t);
     const int t_out = (T - t) / t + 1;
     const int64_t Mtot = (int64_t)B * t_out * (H / 4) * (W / 4);
-    const int ld = (K > C ? K : C) + 1;
-    const size_t lds = (size_t)TM * ld * sizeof(float);
+    const int ld = (K + 1 > C + 4 ? K + 1 : C + 4);
+    const size_t lds = ((size_t)TM * ld + 2 * TM) * sizeof(float);     // patch / output tile + the (mean, rstd) pairs
     MUMPY_REQUIRE(lds <= 160 * 1024, MUMPY_ERANGE, "patch_embed: tile needs %zu B of LDS (t=%d too long)", lds, t);
     if (lds > 64 * 1024) {   // long tubelets (T = 9): raise the dynamic-LDS cap of this kernel (idempotent)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(patch_embed_kernel),

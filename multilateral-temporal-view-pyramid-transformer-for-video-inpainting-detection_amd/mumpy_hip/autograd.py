@@ -70,13 +70,15 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        n, k = weight.shape
+        wshape = weight.shape                                     # (N, K), or a 1x1-conv kernel (N, K, 1, 1): the same memory
+        n, k = wshape[0], weight.numel() // wshape[0]
+        weight = weight.reshape(n, k)
         dy2, x2 = dy.reshape(-1, n).contiguous(), x.reshape(-1, k)
         need_dx, need_dw, need_db = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if ops.matrix_math() not in ("fp32", "bf16") or LEGACY_LINEAR_BWD:
             # split-precision modes: the forward GEMM on transposed copies (its operand modes apply to the backward products too)
             dx = ops.linear(dy2, ops.transpose(weight)).reshape(x.shape) if need_dx else None
-            dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)) if need_dw else None
+            dw = ops.linear(ops.transpose(dy2, 32), ops.transpose(x2, 32)).reshape(wshape) if need_dw else None
             db = ops.col_sum(dy2) if need_db else None
             return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
         m = dy2.shape[0]
@@ -87,9 +89,12 @@ class LinearFn(torch.autograd.Function):
         dx = dw = db = None
         if (need_dx and not big) or need_dw or need_db:          # (a frozen Linear with a big input needs only the GEMM below)
             dx, dw, db = ops.linear_bwd(x2.contiguous(), weight, dy2, need_dx=need_dx and not big, need_dw=need_dw, need_db=need_db,
-                                        dw_out=wslot if need_dw else None, db_out=bslot if need_db else None)
+                                        dw_out=wslot.reshape(n, k) if (need_dw and wslot is not None) else None,
+                                        db_out=bslot if need_db else None)
         if big:
             dx = ops.linear(dy2, ops.transpose(weight))
+        if dw is not None:
+            dw = dw.reshape(wshape)
         return (dx.reshape(x.shape) if need_dx else None), dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
@@ -556,7 +561,7 @@ def swin_dattention_train(att, x1w, x2w):
     on the (B1,3,49,2) positions are a few KB of torch arithmetic)."""
     b1, _, c = x1w.shape
     g, cg = att.n_groups, att.n_group_channels
-    q = LinearFn.apply(x1w, att.proj_q.weight.reshape(c, c), att.proj_q.bias)
+    q = LinearFn.apply(x1w, att.proj_q.weight, att.proj_q.bias)          # (C,C,1,1) leaf: dW accumulates in its grad slot
     off = att.conv_offset
     qg = q.reshape(b1, 49, g, cg).permute(0, 2, 1, 3).reshape(b1 * g, 49, cg).contiguous()
     u = DWConv5Fn.apply(qg, off[0].weight, off[0].bias)
@@ -569,7 +574,7 @@ def swin_dattention_train(att, x1w, x2w):
     bkv = torch.cat([att.proj_k.bias, att.proj_v.bias])
     kv = LinearFn.apply(samp, wkv, bkv)
     o = DeformAttentionFn.apply(q, kv, att.scale)
-    yt = LinearFn.apply(o, att.proj_out.weight.reshape(c, c), att.proj_out.bias)
+    yt = LinearFn.apply(o, att.proj_out.weight, att.proj_out.bias)
     return yt.transpose(1, 2).reshape(b1, 49, c)
 
 
