@@ -441,10 +441,10 @@ def main():
         # WRITE_SIZE; tools/pmc_bench.sh + tools/summarize_pmc_bench.py -> profiles/): bench.py cannot run rocprofv3 on itself
         dom["traffic"] = None
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_bench_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_pmc_bench_traffic.json")))
             if args.math == "fp32" and args.batch == 8 and args.frames == 5 and dom["kernel"] in pmc:
                 dom["traffic"] = pmc[dom["kernel"]]["hbm_bytes_per_launch"]
-                dom["traffic_unit"] = "B per launch (PMC: profiles/r02_pmc_bench_traffic.md)"
+                dom["traffic_unit"] = "B per launch (PMC: profiles/r03_pmc_bench_traffic.md)"
         except OSError:
             pass
         dom.pop("launches", None)

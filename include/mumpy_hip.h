@@ -161,6 +161,14 @@ int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int64_t block_
                           const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
                           void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Rows mode with a SEGMENTED contraction index: row (blk, r) of the A operand is K / kseg segments of kseg floats, segment j at
+ * x + blk * block_stride + j * kstride + r * kseg.  E.g. the (B, T, n, C) token tensor as the (B n) x (T C) operand of a
+ * Conv3d(k = s = (T,1,1)) head (decoder.py:62-66): rows_per_block = n, block_stride = T n C, kseg = C, kstride = n C, W =
+ * the kernel re-laid (Cout, T, C).  kseg % 32 == 0, K % kseg == 0.  One launch instead of T chained mumpy_linear_rows_fwd. */
+int mumpy_linear_rows_kseg_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, int kseg, int kstride, const float* W,
+                               const float* bias, const float* residual, float* y, int64_t M, int N, int K, int act,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Convolution, NHWC, stride 1, zero "same" padding, odd kernel: y = act(conv(x, w) + bias) + residual
  *      — the decoder's 3x3 / 7x1 / 1x7 nn.Conv2d (decoder.py:9,24-31,68-95,149-178) as an implicit GEMM on the
  *      mumpy_linear_fwd tile machinery (K index = (tap, channel); borders predicated, nothing is unfolded).

@@ -56,6 +56,10 @@ constexpr int LDR = 36;  // LDS row stride in dwords
 // predicate.  The weight is the channels_last (KRSC) image of the nn.Conv2d kernel == an (N, K) row-major matrix.
 struct ConvGeom {
     int H, W, Cin, kh, kw, ph, pw;
+    // plain GEMM with a SEGMENTED contraction index (rows mode only): k = (segment j, c), c < kseg, and segment j of a row lives
+    // kstride floats after segment j - 1 -- the (B, T, n, C) token tensor as the (B n) x (T C) operand of a Conv3d(k = s = (T,1,1))
+    // head (decoder.py:62-66) without a copy.  kseg = 0: dense rows of K floats.  kseg % 32 == 0 (a chunk stays in a segment).
+    int kseg, kstride;
 };
 
 // waves per SIMD the register allocator must leave room for: 8 waves (one block) per CU for the 128x128 tile,
@@ -189,10 +193,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
             arow[i] = X + m * cg.Cin + 4 * ld_c4;
         } else {
             ayx[i] = 0;
-            if (rpb >= M) arow[i] = X + m * K + 4 * ld_c4;                   // dense
+            if (rpb >= M && !cg.kseg) arow[i] = X + m * K + 4 * ld_c4;       // dense
             else {
                 const unsigned mu = (unsigned)m, blk = mu / (unsigned)rpb;
-                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * K + 4 * ld_c4;
+                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * (cg.kseg ? cg.kseg : K) + 4 * ld_c4;
             }
         }
     }
@@ -224,9 +228,10 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)&lds[buf][(wave_row + RPI * i) * LD], 16, 0, 0);
             }
         } else {
+            const int ka = cg.kseg ? (k0 / cg.kseg) * cg.kstride + k0 % cg.kseg : k0;     // (wave-uniform)
 #pragma unroll
             for (int i = 0; i < A_LD; ++i)
-                __builtin_amdgcn_global_load_lds((gptr_t)(arow[i] + k0 + asw[i]), (lptr_t)&lds[buf][(wave_row + RPI * i) * LD], 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(arow[i] + ka + asw[i]), (lptr_t)&lds[buf][(wave_row + RPI * i) * LD], 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i)
@@ -245,8 +250,9 @@ __global__ __launch_bounds__(64 * (BM / WM) * (BN / WN), (BM * BN > 64 * 64) ? 2
                 areg[i] = ok ? v : f32x4{0, 0, 0, 0};
             }
         } else {
+            const int ka = cg.kseg ? (k0 / cg.kseg) * cg.kstride + k0 % cg.kseg : k0;     // (wave-uniform)
 #pragma unroll
-            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + ka);
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
@@ -473,10 +479,10 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
             arow[i] = X + m * cg.Cin + 4 * ld_c4;
         } else {
             ayx[i] = 0;
-            if (rpb >= M) arow[i] = X + m * K + 4 * ld_c4;                   // dense
+            if (rpb >= M && !cg.kseg) arow[i] = X + m * K + 4 * ld_c4;       // dense
             else {
                 const unsigned mu = (unsigned)m, blk = mu / (unsigned)rpb;
-                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * K + 4 * ld_c4;
+                arow[i] = X + (int64_t)blk * bstride + (int64_t)(mu - blk * (unsigned)rpb) * (cg.kseg ? cg.kseg : K) + 4 * ld_c4;
             }
         }
     }
@@ -507,8 +513,9 @@ __global__ __launch_bounds__(256, 2) void linear_bf16_kernel(const float* __rest
                 areg[i] = ok ? v : f32x4{0, 0, 0, 0};
             }
         } else {
+            const int ka = cg.kseg ? (k0 / cg.kseg) * cg.kstride + k0 % cg.kseg : k0;     // (wave-uniform)
 #pragma unroll
-            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + k0);
+            for (int i = 0; i < A_LD; ++i) areg[i] = *reinterpret_cast<const f32x4*>(arow[i] + ka);
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) breg[i] = *reinterpret_cast<const f32x4*>(brow[i] + k0);
@@ -757,9 +764,11 @@ int ws_plan(int64_t M, int N, int K, bool have_ws, bool conv) {
 
 int launch_linear(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N,
                   int K, int act, float* ws, int64_t ws_bytes, hipStream_t s, int64_t rpb = 0, int64_t bstride = 0,
-                  const ConvGeom* conv = nullptr, bool ws_clean = false, const gemm_ws::LnArgs* ln = nullptr) {
+                  const ConvGeom* conv = nullptr, bool ws_clean = false, const gemm_ws::LnArgs* ln = nullptr, int kseg = 0,
+                  int kstride = 0) {
     if (rpb <= 0) { rpb = M; bstride = 0; }
-    const ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0};
+    ConvGeom cg = conv ? *conv : ConvGeom{0, 0, 0, 0, 0, 0, 0, 0, 0};
+    cg.kseg = kseg; cg.kstride = kstride;
     const bool math_bf16 = (act & MUMPY_MATH_BF16) != 0;
     const bool math_x2 = (act & MUMPY_MATH_BF16X2) != 0;
     const bool math_x3 = (act & MUMPY_MATH_BF16X3) != 0 || math_x2;      // the two-piece mode shares the three-piece planner
@@ -776,7 +785,7 @@ int launch_linear(const float* x, const float* W, const float* bias, const float
         set_error("linear: LayerNorm folding needs a shape the persistent 128x128 kernel takes (mumpy_linear_ln_tiles) in fp32 mode");
         return MUMPY_EINVAL;
     }
-    if (rpb >= M && !math_bf16 && !math_x3 && (conv ? gemm_ws::conv_eligible(M, N, cvd) : gemm_ws::eligible(M, N, K))) {
+    if (rpb >= M && !kseg && !math_bf16 && !math_x3 && (conv ? gemm_ws::conv_eligible(M, N, cvd) : gemm_ws::eligible(M, N, K))) {
         const int num_cu = device_cus();
         const bool have_ws = ws && ws_bytes >= gemm_ws::workspace_bytes(num_cu);
         const int how = ws_plan(M, N, K, have_ws, conv != nullptr);           // 0: tiled kernels, 1: whole tiles, 2: split
@@ -943,7 +952,7 @@ extern "C" int mumpy_linear_bf16s_fwd(const void* x, const void* W, const float*
     const float* xf = static_cast<const float*>(x);
     const float* wf = static_cast<const float*>(W);
     float* yf = static_cast<float*>(y);
-    const ConvGeom cg{0, 0, 0, 0, 0, 0, 0};
+    const ConvGeom cg{0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipStream_t s = as_stream(stream);
     MUMPY_REQUIRE(!(out_bf16 && residual), MUMPY_EINVAL, "linear_bf16s: a bf16 output takes no residual");
     // every eligible shape (K % 64 == 0, K >= 192): the persistent wave-specialised kernel with bf16 stages (gemm_ws.h).  With
@@ -1051,6 +1060,24 @@ extern "C" int mumpy_linear_rows_fwd(const float* x, int64_t rows_per_block, int
                          workspace ? workspace_bytes : 0, as_stream(stream), rows_per_block, block_stride);
 }
 
+// Rows mode with a segmented contraction index: row (blk, r) of the A operand is the concatenation of K / kseg segments of kseg
+// floats, segment j at  x + blk * block_stride + j * kstride + r * kseg  -- e.g. the (B, T, n, C) token tensor read as the
+// (B n) x (T C) operand of a Conv3d(k = s = (T,1,1)) head (decoder.py:62-66): rows_per_block = n, block_stride = T n C, kseg = C,
+// kstride = n C.  One launch instead of T chained GEMMs (each re-reading and re-writing y).
+extern "C" int mumpy_linear_rows_kseg_fwd(const float* x, int64_t rows_per_block, int64_t block_stride, int kseg, int kstride,
+                                          const float* W, const float* bias, const float* residual, float* y, int64_t M, int N, int K,
+                                          int act, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (M == 0) return 0;
+    if (int rc = check_linear_args(x, W, residual, y, M, N, K, act)) return rc;
+    MUMPY_REQUIRE(rows_per_block > 0 && M % rows_per_block == 0 && block_stride % 4 == 0, MUMPY_EINVAL,
+                  "linear_rows_kseg: M=%lld must be a multiple of rows_per_block=%lld and block_stride %% 4 == 0",
+                  (long long)M, (long long)rows_per_block);
+    MUMPY_REQUIRE(kseg > 0 && kseg % 32 == 0 && K % kseg == 0 && kstride % 4 == 0 && kstride >= 0, MUMPY_EINVAL,
+                  "linear_rows_kseg: need kseg %% 32 == 0, K %% kseg == 0, kstride %% 4 == 0 (got kseg=%d K=%d kstride=%d)", kseg, K, kstride);
+    return launch_linear(x, W, bias, residual, y, M, N, K, act, static_cast<float*>(workspace), workspace ? workspace_bytes : 0,
+                         as_stream(stream), rows_per_block, block_stride, nullptr, false, nullptr, kseg, kstride);
+}
+
 extern "C" int64_t mumpy_conv2d_workspace_bytes(int B, int H, int W, int Cin, int Cout, int kh, int kw) {
     return mumpy_linear_workspace_bytes((int64_t)B * H * W, Cout, kh * kw * Cin);
 }
@@ -1065,7 +1092,7 @@ extern "C" int mumpy_conv2d_nhwc_fwd(const float* x, const float* w_krsc, const 
     const int K = kh * kw * Cin;
     if (int rc = check_linear_args(x, w_krsc, residual, y, M, Cout, K, act)) return rc;
     MUMPY_REQUIRE(aligned16(workspace), MUMPY_EALIGN, "conv2d: workspace must be 16-byte aligned");
-    const ConvGeom cg{H, W, Cin, kh, kw, kh / 2, kw / 2};
+    const ConvGeom cg{H, W, Cin, kh, kw, kh / 2, kw / 2, 0, 0};
     return launch_linear(x, w_krsc, bias, residual, y, M, Cout, K, act, static_cast<float*>(workspace),
                          workspace ? workspace_bytes : 0, as_stream(stream), 0, 0, &cg);
 }

@@ -152,11 +152,10 @@ class Decoder(nn.Module):
             if tv == 1:       # same tokens at every time step -> one GEMM with the T weight slices summed
                 wv = self._cached(("h", idx, v), (w,), lambda: w[:, c0:c0 + c, :, 0, 0].sum(2).contiguous())
                 y = ops.linear(x.reshape(b * n, c), wv, conv.bias if y is None else None, residual=y)
-            elif tv == tmax:  # one GEMM per time slice over the strided (B, n, C) view, accumulated via the residual
-                xv = x.reshape(b, tv, n, c)
-                for tt in range(tv):
-                    wt = self._cached(("h", idx, v, tt), (w,), lambda: w[:, c0:c0 + c, tt, 0, 0].contiguous())
-                    y = ops.linear_rows(xv[:, tt], wt, conv.bias if y is None else None, residual=y)
+            elif tv == tmax:  # ONE GEMM over all time slices: K index (t, c), the tokens' t-slices are K segments of the A rows
+                wt = self._cached(("h", idx, v, "t"), (w,),
+                                  lambda: w[:, c0:c0 + c, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], tv * c).contiguous())
+                y = ops.linear_time_slices(x.reshape(b, tv, n, c), wt, conv.bias if y is None else None, residual=y)
             else:
                 raise NotImplementedError("views must have temporal dim 1 or max (true for every Mumpy config)")
             c0 += c

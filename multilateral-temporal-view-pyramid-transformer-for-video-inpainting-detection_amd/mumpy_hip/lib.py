@@ -28,6 +28,7 @@ SIGNATURES = {
     "mumpy_linear_ln_tiles": [c_l, c_i, c_i],
     "mumpy_linear_lnx_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f, c_f, c_i, c_f, c_fl, c_f],
     "mumpy_linear_rows_fwd": [c_f, c_l, c_l, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
+    "mumpy_linear_rows_kseg_fwd": [c_f, c_l, c_l, c_i, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_gn_stats_nhwc_fwd": [c_f, c_f, c_i, c_l, c_i, c_i, c_i, c_f],
     "mumpy_gn_apply_resample_nhwc_fwd": [c_f, c_f, c_i, c_f, c_f, c_i, c_fl, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_i, c_i,
                                          c_i, c_i, c_i, c_i, c_f],

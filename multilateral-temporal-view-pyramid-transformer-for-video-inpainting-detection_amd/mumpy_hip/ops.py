@@ -316,6 +316,28 @@ def linear_rows(x_view, weight, bias=None, residual=None, out=None):
     return out
 
 
+def linear_time_slices(x4, weight, bias=None, residual=None):
+    """x4 (B, T, n, C) contiguous, weight (N, T*C) with K index (t, c): y[(b, i), :] = sum_t x4[b, t, i, :] @ weight[:, t*C:(t+1)*C].T
+    -- a Conv3d(k = s = (T,1,1)) head on channels-last tokens (decoder.py:62-66) in ONE launch (segmented-K rows mode)."""
+    x4, weight = _chk(x4, "x"), _chk(weight, "weight")
+    b, t, n, c = x4.shape
+    nout, k = weight.shape
+    if k != t * c or c % 32:
+        raise RuntimeError(f"linear_time_slices: weight expects K = T*C = {t * c} (got {k}); C % 32 == 0")
+    m = b * n
+    out = torch.empty(m, nout, device=x4.device, dtype=torch.float32)
+    if residual is not None:
+        residual = _chk(residual, "residual")
+    key = (m, nout, k)
+    wsb = _WS_BYTES.get(key)
+    if wsb is None:
+        wsb = _WS_BYTES[key] = int(_lib().mumpy_linear_workspace_bytes(m, nout, k))
+    ws = torch.empty(wsb // 4, device=x4.device, dtype=torch.float32) if wsb else None
+    _call("mumpy_linear_rows_kseg_fwd", _p(x4), n, t * n * c, c, n * c, _p(weight), _p(None if bias is None else _chk(bias, "bias")),
+          _p(residual), _p(out), m, nout, k, ACT_NONE | _MATH, _p(ws), wsb, _stream(), work=2.0 * m * nout * k)
+    return out
+
+
 def conv2d_nhwc(x, w_krsc, bias=None, act=ACT_NONE, residual=None):
     """x logical (B,Cin,H,W) with NHWC memory; w_krsc (Cout,kh,kw,Cin) contiguous; stride 1, same padding.
     Returns logical (B,Cout,H,W) with NHWC memory."""

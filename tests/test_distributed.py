@@ -120,3 +120,39 @@ def test_bench_rejects_mismatched_world_before_touching_a_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], env=env, capture_output=True,
                        text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_rccl_backend_executes_on_this_gpu():
+    """The `nccl` (= RCCL) branch of the launch path on real hardware: a ONE-rank RCCL process group on cuda:0 (RCCL refuses two
+    ranks on one device, and a gpurun box has one GPU) -- init with device_id, the metric all-reduce and the max-over-ranks timing
+    reduction on device tensors, a barrier, teardown.  It cannot show scaling; it shows that the code the driver's N-GPU run takes
+    (distributed.init_process_group("nccl", dev), all_reduce_metric on a GPU tensor) runs through RCCL on this image."""
+    import subprocess
+    import sys
+    from conftest import PKG, ROOT
+    code = r'''
+import os, sys, datetime, torch, torch.distributed as dist
+sys.path[:0] = [%r, %r]
+from mumpy_hip import distributed as D
+os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)      # what D.init_process_group does for world > 1
+assert dist.get_backend() == "nccl"
+pred = torch.rand(4, 1, 32, 32, device=dev) > 0.5
+gt = torch.rand(4, 1, 32, 32, device=dev) > 0.5
+v = D.eval_metric_vector(pred, gt)
+ref = v.clone()
+dist.all_reduce(v, op=dist.ReduceOp.SUM)                    # the one collective of the path, on a device tensor, through RCCL
+assert torch.equal(v, ref) and v.is_cuda
+assert D.max_over_ranks(1.25, dev) == 1.25
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print("rccl ok")
+''' % (PKG, ROOT)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

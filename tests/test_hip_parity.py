@@ -405,6 +405,19 @@ def test_deform_fused_gemms_match_the_unfused_kernels(c, side, r):
     assert rel_err(got.cpu(), ref.cpu()) < 2e-5
 
 
+@pytest.mark.parametrize("b,t,n,c,nout", [(2, 5, 196, 128, 256), (1, 5, 49, 1024, 256), (8, 3, 784, 256, 256), (3, 9, 49, 96, 64)])
+def test_linear_time_slices_segmented_k(b, t, n, c, nout):
+    """mumpy_linear_rows_kseg_fwd: the (B,T,n,C) token tensor as the (B n) x (T C) operand of a Conv3d(k = s = (T,1,1)) head
+    (decoder.py:62-66) without a copy and in one launch -- against float64 of the per-slice sum, incl. one block (B = 1), the deep-K
+    split plans and bias + residual."""
+    x = seeded_randn(60 + c, b, t, n, c)
+    w = seeded_randn(61, nout, t * c) / (t * c) ** 0.5
+    bias, res = seeded_randn(62, nout), seeded_randn(63, b * n, nout)
+    ref = sum(x[:, tt].reshape(b * n, c).double() @ w[:, tt * c:(tt + 1) * c].double().t() for tt in range(t)) + bias.double() + res.double()
+    got = ops.linear_time_slices(x.to(DEV), w.to(DEV), bias.to(DEV), residual=res.to(DEV))
+    assert got.shape == (b * n, nout) and rel_err(got.cpu(), ref) < 1e-5
+
+
 def test_kept_workspace_status_word():
     """The sticky status word of a kept GEMM workspace: zero after split-schedule launches (M = 1960: every tile is cut across
     workgroups), non-zero values are reported by ops.check_workspaces() as an error and the workspaces are re-zeroed."""
