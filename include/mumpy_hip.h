@@ -65,6 +65,18 @@ int         mumpy_tuning_build(void);
  * two-launch route (mumpy_layernorm_fwd + mumpy_linear_wsz_fwd) for such data; the word is sticky until re-zeroed. */
 int mumpy_workspace_status(const void* workspace, int* status);
 
+/* ---- "background" kernels: NO LDS, so that they can be resident beside the persistent GEMM (round 3) ----
+ * The persistent GEMM behind mumpy_linear_wsz_fwd holds every CU's whole LDS; a kernel that allocates any LDS runs strictly after
+ * it, an LDS-free one overlaps (tools/coresidency_probe.py).  For work forked beside a chain of large GEMMs (views 1 / 2 beside
+ * view 3 inside a pyramid stage, mTVE:445-450) the caller may ask for these forms; results equal the regular entry points'.
+ * mumpy_linear_rd_fwd: y = act(x W^T + bias) + residual, fp32 MFMA, operands straight from global memory into registers; no
+ * workspace, no planner: slower than mumpy_linear_fwd when it runs alone.  K % 32 == 0, N % 32 == 0. */
+int mumpy_linear_rd_fwd(const float* x, const float* W, const float* bias, const float* residual, float* y, int64_t M, int N, int K,
+                        int act, void* stream);
+/* mumpy_window_attention_fwd without LDS (token tables in registers, bias rows from L1). */
+int mumpy_window_attention_bg_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab, const int32_t* mask_id,
+                                  int n_mask, int B, int Hs, int W, int C, int shift, float scale, void* stream);
+
 /* ---- LayerNorm folded into the GEMMs either side of it (round 3; swin:266,305: x + f(norm(x)) chains) ----
  * A pre-norm block computes  y = act(LayerNorm(x) W^T + b)  right after a residual GEMM produced x.  Instead of a LayerNorm
  * launch (one read + one write of x between two GEMMs):

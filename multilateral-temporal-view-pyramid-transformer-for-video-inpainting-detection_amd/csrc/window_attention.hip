@@ -207,8 +207,12 @@ __device__ __forceinline__ const f32x4* at16(const char* base, uint32_t off) {
 // DBG = false is the shipped instantiation: the MUMPY_WA_DBG ablation switches (skip loads / MFMAs / stores) exist only in
 // the diagnostic instantiation, which the launcher selects when that variable is set.
 // IO16: qkv and out are bf16 in memory (config 3's activation storage); the arithmetic is the same fp32 MFMA flow.
-template <bool DBG, bool IO16 = false>
-__global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
+// NOLDS: the "background" instantiation (round 3, see gemm_rd.hip): no LDS allocation at all, so that the kernel can be resident on
+// a CU whose whole LDS belongs to the persistent GEMM.  The per-wave token tables live in registers and are read through
+// ds_bpermute (which uses the LDS crossbar but no LDS memory); the bias rows come from global memory / L1.  Slower per unit (the
+// row-strided bias reads cost L1 tag cycles), used only for the small launches of views 1 / 2 that run beside view 3's GEMMs.
+template <bool DBG, bool IO16 = false, bool NOLDS = false>
+__global__ __launch_bounds__(256, (NOLDS ? 4 : 3)) void win_attn_self_kernel(SelfArgs a) {
     __shared__ uint32_t tok_in[4][64];    // token * (3C*4): byte offset of the token's qkv row
     __shared__ __attribute__((aligned(16))) uint32_t tok_out[4][64];   // token * (C*4):  byte offset of the token's out row
     __shared__ __attribute__((aligned(16))) float bias_s[WT * BLD];
@@ -221,27 +225,30 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
     const int head = blockIdx.x % a.nH;
     const int slot = blockIdx.x / a.nH;
     const int64_t nwin = (int64_t)a.B * a.nW;
-    {   // bias table: staged ONCE per persistent block
+    if (!NOLDS) {   // bias table: staged ONCE per persistent block
         const float* bsrc = a.bias + (int64_t)head * 4096;
         for (int idx = threadIdx.x; idx < WT * 16; idx += 256) {
             const int row = idx >> 4, c4 = idx & 15;
             *reinterpret_cast<f32x4*>(&bias_s[row * BLD + 4 * c4]) = *reinterpret_cast<const f32x4*>(bsrc + row * 64 + 4 * c4);
         }
+        __syncthreads();
     }
-    __syncthreads();
     for (int d = 0; d < (slot % 3) * a.stagger; ++d) __builtin_amdgcn_s_sleep(127);
     const int64_t L = (int64_t)a.Hs * a.W;
     const uint32_t rsb = (IO16 ? 6u : 12u) * a.C, rob = (IO16 ? 2u : 4u) * a.C;                      // row strides in bytes
-    uint32_t* ti = tok_in[wave];
-    uint32_t* to = tok_out[wave];
+    uint32_t* ti = NOLDS ? nullptr : tok_in[wave];
+    uint32_t* to = NOLDS ? nullptr : tok_out[wave];
+    uint32_t ti_reg = 0, to_reg = 0;                 // NOLDS: lane l holds table entry l
+    auto TI = [&](int i) -> uint32_t { return NOLDS ? (uint32_t)__shfl((int)ti_reg, i) : ti[i]; };
+    auto TO = [&](int i) -> uint32_t { return NOLDS ? (uint32_t)__shfl((int)to_reg, i) : to[i]; };
     for (int64_t bw = (int64_t)slot * 4 + wave; bw < nwin; bw += (int64_t)a.groups * 4) {   // all scalar
     const int n = (int)(bw % a.nW);
     const int64_t b = bw / a.nW;
     const int wy = n / a.nWx, wx = n - wy * a.nWx;
     {
         const uint32_t tok = (uint32_t)window_token(wy, wx, lane < WT ? lane : WT - 1, a.Hs, a.W, a.shift);   // padded slots -> slot 48
-        ti[lane] = tok * rsb;
-        to[lane] = tok * rob;
+        if (NOLDS) { ti_reg = tok * rsb; to_reg = tok * rob; }
+        else { ti[lane] = tok * rsb; to[lane] = tok * rob; }
     }
     __builtin_amdgcn_wave_barrier();
     const char* base = IO16 ? reinterpret_cast<const char*>(reinterpret_cast<const __bf16*>(a.qkv) + b * L * 3 * a.C + head * HD)
@@ -262,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
             const char* kbase = base + 2 * a.C;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const uint32_t off = ti[32 * t + c] + 32u * h;
+                const uint32_t off = TI(32 * t + c) + 32u * h;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     widen(*reinterpret_cast<const u32x4v*>(base + (off + 16u * i)), qf[t][2 * i], qf[t][2 * i + 1]);
@@ -271,14 +278,14 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
             }
             const char* vbase = base + 4 * a.C;
             for_pv_steps([&](int jt, int g, int e) {
-                const uint32_t w = *reinterpret_cast<const uint16_t*>(vbase + (ti[32 * jt + 8 * g + 4 * h + e] + 2u * c));
+                const uint32_t w = *reinterpret_cast<const uint16_t*>(vbase + (TI(32 * jt + 8 * g + 4 * h + e) + 2u * c));
                 vf[jt][4 * g + e] = __uint_as_float(w << 16);
             });
         } else {
         const char* kbase = base + 4 * a.C;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const uint32_t off = ti[32 * t + c] + 64u * h;
+            const uint32_t off = TI(32 * t + c) + 64u * h;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 qf[t][i] = *at16(base, off + 16u * i);
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
         }
         const char* vbase = base + 8 * a.C;
         for_pv_steps([&](int jt, int g, int e) {
-            vf[jt][4 * g + e] = *reinterpret_cast<const float*>(vbase + (ti[32 * jt + 8 * g + 4 * h + e] + 4u * c));
+            vf[jt][4 * g + e] = *reinterpret_cast<const float*>(vbase + (TI(32 * jt + 8 * g + 4 * h + e) + 4u * c));
         });
         }
     } else {
@@ -320,7 +327,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
             if (!(dbg & 2)) qk_product(s, kf, qf[it]);
             else { s[0][0] = kf[0][0][0] + qf[it][0][0]; s[1][3] = kf[1][1][1] * qf[it][2][1]; }
             const int qi = 32 * it + c;
-            const float* brow = &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];    // padded queries re-read row 48
+            const float* brow = NOLDS ? a.bias + (int64_t)head * 4096 + (qi < WT ? qi : WT - 1) * 64 + 4 * h
+                                      : &bias_s[(qi < WT ? qi : WT - 1) * BLD + 4 * h];    // padded queries re-read row 48
             if (!(dbg & 2))
                 bias_softmax<MASKED>(s, [&](int jt, int g) {
                     f32x4 bv = *reinterpret_cast<const f32x4*>(brow + 32 * jt + 8 * g);
@@ -338,7 +346,14 @@ __global__ __launch_bounds__(256, 3) void win_attn_self_kernel(SelfArgs a) {
                 u32x4v to4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-                    if (!(it == 1 && g == 3)) to4[g] = *reinterpret_cast<const u32x4v*>(&to[32 * it + 8 * g + 4 * h]);
+                    if (!(it == 1 && g == 3)) {
+                        if (NOLDS) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) to4[g][e] = TO(32 * it + 8 * g + 4 * h + e);
+                        } else {
+                            to4[g] = *reinterpret_cast<const u32x4v*>(&to[32 * it + 8 * g + 4 * h]);
+                        }
+                    }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (it == 1 && (r >> 2) >= 2 && !((r >> 2) == 2 && (r & 3) == 0)) continue;  // statically >= 49
@@ -918,7 +933,7 @@ __global__ __launch_bounds__(256) void relpos_bias_expand_kernel(const float* __
 
 }  // namespace
 
-static int window_attention_launch(bool io16, const float* qkv, float* out, const float* bias, const float* mask_tab,
+static int window_attention_launch(int kind, const float* qkv, float* out, const float* bias, const float* mask_tab,
                                           const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
                                           float scale, void* stream) {
     MUMPY_REQUIRE(qkv && out && bias, MUMPY_ENULL, "window_attention: null pointer");
@@ -946,7 +961,9 @@ static int window_attention_launch(bool io16, const float* qkv, float* out, cons
     if (groups > quads) groups = quads;
     a.groups = (int)groups; a.stagger = wa_stagger;
     const int64_t grid = groups * a.nH;
-    if (io16) hipLaunchKernelGGL((win_attn_self_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    const bool io16 = kind == 1;
+    if (kind == 2) hipLaunchKernelGGL((win_attn_self_kernel<false, false, true>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    else if (io16) hipLaunchKernelGGL((win_attn_self_kernel<false, true>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     else if (dbgmask) hipLaunchKernelGGL((win_attn_self_kernel<true, false>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     else hipLaunchKernelGGL((win_attn_self_kernel<false, false>), dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
     MUMPY_CHECK_LAUNCH("window_attention");
@@ -956,14 +973,22 @@ static int window_attention_launch(bool io16, const float* qkv, float* out, cons
 extern "C" int mumpy_window_attention_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
                                           const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
                                           float scale, void* stream) {
-    return window_attention_launch(false, qkv, out, bias, mask_tab, mask_id, n_mask, B, Hs, W, C, shift, scale, stream);
+    return window_attention_launch(0, qkv, out, bias, mask_tab, mask_id, n_mask, B, Hs, W, C, shift, scale, stream);
+}
+
+// "Background" form: identical arithmetic and results, NO LDS allocation (token tables in registers via ds_bpermute, bias rows from
+// L1), so that the launch can be resident beside the persistent GEMM, which owns every CU's whole LDS (see gemm_rd.hip).
+extern "C" int mumpy_window_attention_bg_fwd(const float* qkv, float* out, const float* bias, const float* mask_tab,
+                                             const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
+                                             float scale, void* stream) {
+    return window_attention_launch(2, qkv, out, bias, mask_tab, mask_id, n_mask, B, Hs, W, C, shift, scale, stream);
 }
 
 // bf16 STORAGE: qkv (B, Hs*W, 3C) and out (B, Hs*W, C) are bf16; bias / mask tables fp32; same arithmetic.
 extern "C" int mumpy_window_attention_bf16_fwd(const void* qkv, void* out, const float* bias, const float* mask_tab,
                                                const int32_t* mask_id, int n_mask, int B, int Hs, int W, int C, int shift,
                                                float scale, void* stream) {
-    return window_attention_launch(true, static_cast<const float*>(qkv), static_cast<float*>(out), bias, mask_tab, mask_id, n_mask,
+    return window_attention_launch(1, static_cast<const float*>(qkv), static_cast<float*>(out), bias, mask_tab, mask_id, n_mask,
                                    B, Hs, W, C, shift, scale, stream);
 }
 

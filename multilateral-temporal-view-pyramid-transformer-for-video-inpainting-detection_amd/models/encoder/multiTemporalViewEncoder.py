@@ -222,8 +222,14 @@ class MultiViewBasicLayer(nn.Module):
         x = self.blocks[0](x)                               # cross-view block: view 3 -> 2 -> 1 dependency chain
         # the three views are independent from here to the end of the stage: fork them (view 3, the heaviest, stays on
         # the current stream)
-        res = run_parallel([lambda: self._view_chain(0, x[0]), lambda: self._view_chain(1, x[1]),
-                            lambda: self._view_chain(2, x[2])], [(x[0],), (x[1],), (x[2],)])
+        # (views 1 / 2 run beside view 3's persistent GEMMs, which own every CU's LDS: they take the LDS-free "background" kernels)
+        def bg(v):
+            from mumpy_hip import streams
+            if streams.SERIAL:
+                return self._view_chain(v, x[v])
+            with ops.background():
+                return self._view_chain(v, x[v])
+        res = run_parallel([lambda: bg(0), lambda: bg(1), lambda: self._view_chain(2, x[2])], [(x[0],), (x[1],), (x[2],)])
         return [r[0] for r in res], [r[1] for r in res]
 
 

@@ -22,6 +22,8 @@ SIGNATURES = {
     "mumpy_window_attention_bf16_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_linear_ws_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_linear_wsz_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
+    "mumpy_linear_rd_fwd": [c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f],
+    "mumpy_window_attention_bg_fwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_linear_workspace_bytes": [c_l, c_i, c_i],
     "mumpy_tuning_build": [],
     "mumpy_workspace_status": [c_f, ctypes.POINTER(ctypes.c_int)],

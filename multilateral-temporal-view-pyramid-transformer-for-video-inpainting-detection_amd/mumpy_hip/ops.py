@@ -163,6 +163,10 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None, emit_sta
         residual = _chk(residual, "residual")
         if residual.numel() != m * n:
             raise RuntimeError("linear: residual shape mismatch")
+    if _in_background():
+        _call("mumpy_linear_rd_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual), _p(out), m, n, k,
+              act, _stream(), work=2.0 * m * n * k)
+        return out
     key = (m, n, k)
     wsb = _WS_BYTES.get(key)
     if wsb is None:
@@ -183,6 +187,32 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, out=None, emit_sta
     _call("mumpy_linear_wsz_fwd", _p(x), _p(weight), _p(None if bias is None else _chk(bias, "bias")), _p(residual),
           _p(out), m, n, k, act | _MATH, _p(ws), 0 if ws is None else ws.numel() * 4, _stream(), work=2.0 * m * n * k)
     return out
+
+
+# ---- "background" kernels (no LDS: resident beside the persistent GEMM, csrc/gemm_rd.hip) ---------------------------------------
+_BACKGROUND = [0]
+# Measured and NOT adopted (default off; profiles/r03_coresidency_probe.txt): the LDS-free GEMM is resident-compatible with the
+# persistent kernel but two MFMA-bound kernels gain nothing from sharing a CU (together = sum on the two-stream probe), and alone
+# it is slower than the tiled kernels -- the forward went 21.5 -> 23.3 ms with it.  MUMPY_BACKGROUND=1 turns it on for A/B runs.
+BACKGROUND_ON = __import__("os").environ.get("MUMPY_BACKGROUND", "0") == "1"
+
+
+class background:
+    """Context manager for work that is forked beside a chain of large GEMMs (views 1 / 2 beside view 3 inside a pyramid stage):
+    inside it, fp32 `linear` and `window_attention` launch their LDS-free forms (mumpy_linear_rd_fwd, mumpy_window_attention_bg_fwd),
+    which can be resident on a CU whose whole LDS belongs to the persistent GEMM.  Same results; slower when run alone."""
+
+    def __enter__(self):
+        _BACKGROUND[0] += 1
+        return self
+
+    def __exit__(self, *exc):
+        _BACKGROUND[0] -= 1
+        return False
+
+
+def _in_background():
+    return _BACKGROUND[0] > 0 and BACKGROUND_ON and _MATH == MATH_FP32 and _STORAGE == "fp32"
 
 
 # ---- LayerNorm folded into the GEMMs either side of it (mumpy_linear_lnx_fwd; swin:266,305 / blocks:86-88) -----------------
@@ -557,7 +587,7 @@ def window_attention(qkv, bias_pad, b, hs, w, c, shift, scale, mask_tab=None, ma
         raise RuntimeError("window_attention: qkv shape mismatch")
     out = torch.empty(b, hs * w, c, device=qkv.device, dtype=torch.float32) if out is None else out
     n_mask = 0 if mask_id is None else mask_id.numel()
-    _call("mumpy_window_attention_fwd", _p(qkv), _p(out), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
+    _call("mumpy_window_attention_bg_fwd" if _in_background() else "mumpy_window_attention_fwd", _p(qkv), _p(out), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
           b, hs, w, c, shift, scale, _stream(), work=307328.0 * b * (hs // 7) * (w // 7) * (c // 32))
     return out
 

@@ -418,6 +418,42 @@ def test_linear_time_slices_segmented_k(b, t, n, c, nout):
     assert got.shape == (b * n, nout) and rel_err(got.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("m,n,k,gelu,res", [(1568, 1536, 384, True, False), (1568, 384, 1536, False, True), (392, 2304, 768, False, False),
+                                            (25088, 96, 96, False, True), (1000, 288, 96, True, True), (37, 32, 32, False, False)])
+def test_background_gemm_without_lds(m, n, k, gelu, res):
+    """mumpy_linear_rd_fwd (operands global -> registers, no LDS, resident beside the persistent GEMM): against float64 and against
+    the regular entry point, incl. ragged M (37, 1000 rows), N that is no multiple of the 64-wide wave tile (96, 288), GELU and
+    residual epilogues."""
+    x, w, b = seeded_randn(m, m, k), seeded_randn(n, n, k) / k ** 0.5, seeded_randn(k, n)
+    r = seeded_randn(m + 1, m, n) if res else None
+    ref = F.linear(x.double(), w.double(), b.double())
+    if gelu:
+        ref = F.gelu(ref)
+    if res:
+        ref = ref + r.double()
+    args = (x.to(DEV), w.to(DEV), b.to(DEV))
+    kw = dict(act=ops.ACT_GELU if gelu else ops.ACT_NONE, residual=None if r is None else r.to(DEV))
+    with ops.background():
+        got = ops.linear(*args, **kw)
+    assert rel_err(got.cpu(), ref) < 1e-5
+    assert rel_err(got.cpu(), ops.linear(*args, **kw).cpu()) < 1e-5
+
+
+def test_background_window_attention_is_bit_identical():
+    """mumpy_window_attention_bg_fwd: the LDS-free form (token tables through ds_bpermute, bias rows from L1) performs the same
+    arithmetic in the same order as the regular kernel: bitwise equal, with and without the shift mask."""
+    from models.modules.swinTransformer import build_shift_mask, relative_position_index
+    b, hs, w, c = 8, 14, 14, 384
+    qkv = seeded_randn(70, b, hs * w, 3 * c).to(DEV)
+    bias = ops.expand_relpos_bias(seeded_randn(71, 169, c // 32).to(DEV) * 0.2, relative_position_index(7, 7).to(DEV))
+    tab, ids = ops.compact_attn_mask(build_shift_mask(hs, w, 7, 3).to(DEV))
+    for shift, mt, mi in ((0, None, None), (3, tab, ids)):
+        ref = ops.window_attention(qkv, bias, b, hs, w, c, shift, 32 ** -0.5, mt, mi)
+        with ops.background():
+            got = ops.window_attention(qkv, bias, b, hs, w, c, shift, 32 ** -0.5, mt, mi)
+        assert torch.equal(got, ref)
+
+
 def test_kept_workspace_status_word():
     """The sticky status word of a kept GEMM workspace: zero after split-schedule launches (M = 1960: every tile is cut across
     workgroups), non-zero values are reported by ops.check_workspaces() as an error and the workspaces are re-zeroed."""
