@@ -174,7 +174,8 @@ class GraphedTrainStep:
     """One training step (taped forward, mask loss, backward, AdamW on every group, gradient reset) captured into a hipGraph
     and replayed: at config 5's micro-batch the eager step is bound by ~10^4 host-side launches, not by the GPU.
     `forward_fn(x) -> logits` must be built from mumpy_hip.autograd functions (capture-safe: no host synchronisation).
-    Stochastic depth must be off (a captured mask would repeat).  Learning-rate schedules keep working: the AdamW constants
+    Train mode works: the stochastic-depth masks are drawn by torch's graph-safe Philox generator inside the capture, so every
+    replay draws new ones (test_hip_graphed_train_step_draws_fresh_drop_path_masks).  Learning-rate schedules keep working: the AdamW constants
     are staged into device memory before each replay.  Call `step(x, target)` -> loss3 (device tensor [total, iou, focal])."""
 
     def __init__(self, forward_fn, optimizers, x, target, warmup: int = 3, loss_scale: float = 1.0, all_reduce: bool = False):
