@@ -419,7 +419,7 @@ def main():
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -538,7 +538,7 @@ def main():
             except Exception as e:                   # reported baseline only: never lose the measured line over it
                 out["cpu_baseline"] = {"error": repr(e)[:200]}
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

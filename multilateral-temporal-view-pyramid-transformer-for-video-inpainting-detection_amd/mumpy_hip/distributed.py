@@ -17,7 +17,10 @@ def init_process_group(backend: str = "nccl", device: torch.device = None, timeo
     The rendezvous / collective timeout is explicit (MUMPY_DIST_TIMEOUT seconds, default 300): a rank that never arrives
     makes the others raise within minutes instead of sitting in the store for c10d's 10-30 minute default."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    # MUMPY_FORCE_DIST=1: build the process group even for ONE rank -- the rehearsal of the N-rank code path (RCCL communicator,
+    # barriers, the metric all-reduce, hipGraph capture beside RCCL's watchdog thread) on a box with a single GPU
+    force = os.environ.get("MUMPY_FORCE_DIST", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
@@ -53,7 +56,7 @@ def eval_metric_vector(pred_mask: torch.Tensor, gt_mask: torch.Tensor) -> torch.
 
 def all_reduce_metric(vec: torch.Tensor) -> torch.Tensor:
     """The single collective of the inference path (24 bytes: latency-bound, topology-irrelevant)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         if vec.is_cuda and dist.get_backend() == "gloo":     # CPU rehearsal backend: reduce on the host
             host = vec.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -64,6 +67,6 @@ def all_reduce_metric(vec: torch.Tensor) -> torch.Tensor:
 
 def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -40,7 +40,9 @@ class GraphedForward:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side):
+        # capture_error_mode="thread_local": with a process group alive (one rank per GPU) RCCL's watchdog thread polls events
+        # while this thread captures; in the default "global" mode such a call from ANOTHER thread invalidates the capture
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             self.static_out = self._fwd()
         self.weights_epoch = state.weights_epoch[0]
 

@@ -214,13 +214,13 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.graph_update = None
         if all_reduce:
-            with torch.cuda.graph(self.graph, stream=side):          # (same stream as the warm-up: see GraphedForward._capture)
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):   # (same stream as the warm-up and thread-local capture errors: see GraphedForward._capture)
                 self.loss3 = fwd_bwd()
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=side):
+            with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), stream=side, capture_error_mode="thread_local"):
                 update()
         else:
-            with torch.cuda.graph(self.graph, stream=side):
+            with torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
                 self.loss3 = fwd_bwd()
                 update()
         bump_weights_epoch()

@@ -60,6 +60,13 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
+def rms_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """RMS of the difference over the RMS of the reference: a per-tensor measure that one large element cannot hide behind
+    (rel_err normalises the largest difference by the largest reference value)."""
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+
+
 def check_digest(t: torch.Tensor, store, name, tol):
     from weight_fill import digest
     s, v = digest(t)

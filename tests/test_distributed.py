@@ -156,3 +156,26 @@ print("rccl ok")
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_bench_rank_path_with_a_live_rccl_group_on_one_gpu():
+    """bench.py exactly as a rank of the driver's N-GPU launch runs it -- RANK / WORLD_SIZE / MASTER_* from the environment,
+    backend nccl, RCCL communicator alive while the forward is captured into a hipGraph (RCCL's watchdog thread polls events
+    meanwhile: the capture uses thread-local error mode), barriers around the timed loop, the metric all-reduce and the
+    max-over-ranks reduction through RCCL -- with WORLD_SIZE = 1 forced through the process-group path (MUMPY_FORCE_DIST=1),
+    because a gpurun box has one GPU.  Checks the JSON line's contract fields."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29519", MUMPY_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-alt",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "clips/s" and out["value"] > 50
+    assert out["scaling"] == "weak" and out["eval_metric"]["clips"] == 8 and out["roofline"]["frac"] > 0.3

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import GOLDEN, check_digest, golden_input, rel_err
+from conftest import GOLDEN, check_digest, golden_input, rel_err, rms_err
 from weight_fill import fill_module_, fill_state_dict_, seeded_randn
 
 pytestmark = pytest.mark.gpu
@@ -645,8 +645,8 @@ def _load_filled(module, device):
 
 
 def _check_full(store, tag, logits, feats, fx, vx, dx, tol):
-    assert rel_err(logits, store[tag + "/logits"]) < tol
-    assert rel_err(fx, store[tag + "/final_x"]) < tol
+    assert rel_err(logits, store[tag + "/logits"]) < tol and rms_err(logits, store[tag + "/logits"]) < tol
+    assert rel_err(fx, store[tag + "/final_x"]) < tol and rms_err(fx, store[tag + "/final_x"]) < tol
     check_digest(dx, store, tag + "/dct_x", tol)
     check_digest(feats, store, tag + "/x_feats", tol)
     for s in range(4):
@@ -761,9 +761,6 @@ def test_full_model_b8_t5_vs_oracle_every_view_tensor():
         logits, _ = dec(fx, vx, dx)
         ref = O.full_forward(cpu_sd(enc), cpu_sd(dec), x)
 
-    def rms_err(a, b):
-        a, b = a.double(), torch.as_tensor(b).double()
-        return float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt())
     assert rel_err(logits.cpu(), ref[0]) < TOL and rms_err(logits.cpu(), ref[0]) < TOL
     assert rel_err(fx.cpu(), ref[2]) < TOL and rms_err(fx.cpu(), ref[2]) < TOL
     ref_views = ref[3]
