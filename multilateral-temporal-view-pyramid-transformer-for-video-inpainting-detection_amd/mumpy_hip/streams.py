@@ -9,6 +9,7 @@ Set MUMPY_SERIAL=1 to disable (A/B timing)."""
 import os
 
 import torch
+import torch.distributed
 
 _SIDE = {}
 _DEPTH = [0]            # nesting depth of run_parallel on this (host) thread: nested forks get their own side streams
@@ -21,6 +22,13 @@ def new_distinct_stream(device, avoid=(), priority=0):
     that is already in use, which would make a fork run on its own parent (silently serial) or two graphs share a side
     stream.  Streams drawn and rejected here are dropped again (they are pool members, nothing is destroyed)."""
     taken = {int(h) for h in avoid} | {s.cuda_stream for s in _SIDE.values()}
+    # With a process group alive, stay out of the pool RCCL's own stream comes from (ProcessGroupNCCL draws a NORMAL-priority pool
+    # stream): a capture stream that aliases it made the watchdog thread query a collective's end event "last recorded in a
+    # capturing stream" -- hipErrorCapturedEvent, capture invalidated, process aborted (found by the one-rank RCCL rehearsal of
+    # tools/train_ddp_bench.py --graph, round 3).  All of this module's streams then come from the high-priority pool (equal among
+    # themselves, so the fork/join schedule is unchanged).
+    if priority == 0 and torch.distributed.is_available() and torch.distributed.is_initialized():
+        priority = -1
     for _ in range(64):
         s = torch.cuda.Stream(device=device, priority=priority)
         if s.cuda_stream not in taken:

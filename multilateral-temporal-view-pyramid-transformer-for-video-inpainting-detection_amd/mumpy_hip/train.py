@@ -13,6 +13,8 @@ Reference behaviour reproduced:
 """
 from typing import Dict, Iterable, List, Optional
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -117,7 +119,8 @@ class FlatAdamW:
     def all_reduce_grads(self, bucket_bytes: int = 64 << 20):
         """Sum all-reduce of the flat gradient in buckets (RCCL ring over xGMI: per-link bound, so a few tens of MB per
         call keeps the ring busy without delaying the first bucket); returns the factor AdamW must apply (1/world)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not (dist.is_available() and dist.is_initialized()) or \
+                (dist.get_world_size() == 1 and os.environ.get("MUMPY_FORCE_DIST", "0") != "1"):    # (forced: one-rank RCCL rehearsal)
             return 1.0
         per = max(1, bucket_bytes // 4)
         host = self.grad.is_cuda and dist.get_backend() == "gloo"        # CPU rehearsal backend: stage each bucket on the host

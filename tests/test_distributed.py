@@ -179,3 +179,21 @@ def test_bench_rank_path_with_a_live_rccl_group_on_one_gpu():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "clips/s" and out["value"] > 50
     assert out["scaling"] == "weak" and out["eval_metric"]["clips"] == 8 and out["roofline"]["frac"] > 0.3
+
+
+@pytest.mark.gpu
+def test_train_rank_path_with_a_live_rccl_group_on_one_gpu():
+    """Config 5's launchable job (tools/train_ddp_bench.py --graph) as ONE forced rank: two hipGraphs (forward + backward | AdamW)
+    with the bucketed gradient all-reduce issued through RCCL between their replays, the replica check through RCCL MIN / MAX."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29521", MUMPY_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "train_ddp_bench.py"), "--batch", "1", "--frames", "3", "--steps", "2",
+                        "--math", "bf16", "--graph"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["backend"] == "nccl" and out["graph"] is True and out["replicas_identical_after_steps"] is True
+    assert all(v == v for v in out["loss"])            # finite

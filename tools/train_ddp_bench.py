@@ -62,18 +62,18 @@ def main():
     if args.graph:
         from mumpy_hip.train import GraphedTrainStep
         gs = GraphedTrainStep(lambda xx: decoder_train(dec, *encoder_train(enc, xx))[0], opts, x, target, warmup=max(args.warmup, 2),
-                              all_reduce=world > 1)
+                              all_reduce=world > 1 or os.environ.get("MUMPY_FORCE_DIST", "0") == "1")
         step = gs.step
         args.warmup = 1
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss3 = step()
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
     torch.cuda.synchronize()
     dt = D.max_over_ranks(time.perf_counter() - t0, dev if backend == "nccl" else None)
@@ -82,7 +82,7 @@ def main():
     if backend != "nccl":
         chk = chk.cpu()          # gloo reduces host tensors; RCCL needs the tensor on this rank's GPU
     same = True
-    if world > 1:
+    if dist.is_initialized():
         lo, hi = chk.clone(), chk.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         same = bool(torch.equal(lo, hi))
@@ -91,7 +91,7 @@ def main():
                           "unit": "clips/s", "n_gpus": world, "ms_per_step": round(1e3 * dt / args.steps, 2), "graph": bool(args.graph), "micro_batch": args.batch,
                           "frames": args.frames, "math": args.math, "train_mode": bool(args.train_mode), "backend": backend, "loss": [round(float(v), 5) for v in loss3],
                           "replicas_identical_after_steps": same}))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
