@@ -267,6 +267,9 @@ int mumpy_patch_merge_ln_fwd(const float* x, const float* gamma, const float* be
  * qkv: (S, T, 3*C) with S = B*49 spatial sites, heads of width 64; out: (S, T, C).  T <= 16. */
 int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T, int C, int heads,
                                  float scale, void* stream);
+/* The same with queries for the first Tq <= T temporal tokens only: out (S, Tq, C); keys / values are all T tokens.  The encoder tail
+ * keeps temporal slices 0..2 (mTVE:745), so the last global block computes nothing for t >= 3. */
+int mumpy_temporal_attention_q_fwd(const float* qkv, float* out, int64_t S, int T, int Tq, int C, int heads, float scale, void* stream);
 
 /* ---- Decoder glue in NHWC (decoder.py:67-225): everything between two convolutions ---------------------------
  * gn_stats: x (B,HW,C) NHWC -> partial (B, nsplit, G, 2) = per-slice {sum, sum of squares} of each GroupNorm group

@@ -9,8 +9,10 @@ using namespace mumpy;
 namespace {
 constexpr int TMAX = 16;
 
+// Tq <= T: only the first Tq temporal tokens are queries (out is (S, Tq, C)); keys / values are all T tokens.  The encoder tail keeps
+// temporal slices 0..2 only (mTVE:745), so the LAST global block needs no output for t >= 3.
 __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                            int64_t units, int T, int C, int heads, float scale) {
+                                                            int64_t units, int T, int Tq, int C, int heads, float scale) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * 4 + wave;
     if (u >= units) return;
@@ -27,10 +29,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
             v[t] = r[2 * C];
         }
     }
-    float* ob = out + s * T * C + head * 64 + lane;
+    float* ob = out + s * Tq * C + head * 64 + lane;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        if (t >= T) continue;
+        if (t >= Tq) continue;
         float sc[TMAX];
         float m = -3.0e38f;
 #pragma unroll
@@ -130,16 +132,24 @@ extern "C" int mumpy_temporal_attention_bwd(const float* qkv, const float* dout,
     return 0;
 }
 
+extern "C" int mumpy_temporal_attention_q_fwd(const float* qkv, float* out, int64_t S, int T, int Tq, int C, int heads, float scale,
+                                              void* stream);
 extern "C" int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T, int C, int heads,
                                             float scale, void* stream) {
+    return mumpy_temporal_attention_q_fwd(qkv, out, S, T, T, C, heads, scale, stream);
+}
+
+extern "C" int mumpy_temporal_attention_q_fwd(const float* qkv, float* out, int64_t S, int T, int Tq, int C, int heads, float scale,
+                                              void* stream) {
     MUMPY_REQUIRE(qkv && out, MUMPY_ENULL, "temporal_attention: null pointer");
     MUMPY_REQUIRE(S >= 0 && T >= 1 && T <= TMAX, MUMPY_ERANGE, "temporal_attention: T=%d outside 1..16", T);
+    MUMPY_REQUIRE(Tq >= 1 && Tq <= T, MUMPY_EINVAL, "temporal_attention: Tq=%d outside 1..T=%d", Tq, T);
     MUMPY_REQUIRE(heads > 0 && C == heads * 64, MUMPY_EINVAL, "temporal_attention: need head width 64 (C=%d heads=%d)", C, heads);
     if (S == 0) return 0;
     const int64_t units = S * heads;
     const int64_t grid = (units + 3) / 4;
     MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "temporal_attention: too many sites");
-    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), qkv, out, units, T, C,
+    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), qkv, out, units, T, Tq, C,
                        heads, scale);
     MUMPY_CHECK_LAUNCH("temporal_attention");
     return 0;

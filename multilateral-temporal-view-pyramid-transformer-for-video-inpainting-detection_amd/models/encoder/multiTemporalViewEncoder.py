@@ -289,9 +289,12 @@ class CreateGlobalBlocks(nn.Module):
         self.blocks = nn.ModuleList([Block(g["hidden_size"], g["num_heads"], g["mlp_dim"], dropout_rate, dpr[i])
                                      for i in range(g["num_layers"])])
 
-    def forward(self, x):
-        for blk in self.blocks:
-            x = blk(x)
+    def forward(self, x, keep_t=None):
+        """keep_t: the caller only uses temporal tokens 0 .. keep_t-1 of the result (the encoder tail, mTVE:745): the last block
+        then skips the others' projection / MLP work and returns (S, keep_t, C)."""
+        last = len(self.blocks) - 1
+        for i, blk in enumerate(self.blocks):
+            x = blk(x, keep_t=keep_t) if (i == last and keep_t is not None) else blk(x)
         return x
 
 
@@ -337,13 +340,17 @@ class ThreeViewSwinTransformer(nn.Module):
         t = max(self.input_token_temporal_dims)
         g = ops.merge_views(views, self.input_token_temporal_dims).reshape(b * 49, t, -1)     # one T-token sequence per site
         g = ops.linear(g, self.globalembedding.weight, self.globalembedding.bias)
-        g = self.globalblocks(g).reshape(b, 49, t * 768)
         if t < 3:
             raise RuntimeError("ThreeViewSwinTransformer: the encoder tail takes temporal slices 0,1,2 (mTVE:745): T >= 3")
+        g = self.globalblocks(g, keep_t=3)          # frames 0,1,2 only leave the last block (mTVE:745): (B*49, 3 or T, 768)
+        tk = g.shape[1]
+        g = g.reshape(b, 49, tk * 768)
+        if tk == 3:
+            return g                                                           # already frames 0,1,2 on channels, dense
         if not dense:
-            return g[:, :, :3 * 768]                                           # frames 0,1,2 on channels (mTVE:745)
+            return g[:, :, :3 * 768]
         out = torch.empty(b, 49, 3 * 768, device=g.device, dtype=torch.float32)
-        ops.copy_rows(g, t * 768, out, 3 * 768, b * 49, 3 * 768)
+        ops.copy_rows(g, tk * 768, out, 3 * 768, b * 49, 3 * 768)
         return out
 
     def forward(self, x):

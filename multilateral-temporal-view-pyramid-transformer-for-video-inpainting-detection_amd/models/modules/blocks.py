@@ -4,6 +4,7 @@ The encoder applies these with the 49 spatial sites as the vmapped axis (mTVE:74
 sequence of T temporal tokens.  Here that is simply a (B*49, T, 768) batch: LN -> QKV GEMM -> one T x T attention
 launch for all sites and heads -> proj GEMM(+residual) -> LN -> fc1 GEMM(+GELU) -> fc2 GEMM(+residual).
 """
+import torch
 import torch.nn as nn
 
 from models.modules.layers import Derived, DropPath, refuse_stochastic_depth
@@ -50,9 +51,10 @@ class Attention(nn.Module):
     def unwrapped(self):
         return self
 
-    def forward(self, x, mask=None, residual=None, ln=None):
+    def forward(self, x, mask=None, residual=None, ln=None, keep_t=None):
         """x (S,T,C) -> (attention output after proj (+residual), None); the TxT map is not materialised.
-        ln = (stats, norm): x is the RAW block input and the LayerNorm is folded into the qkv GEMM (ops.linear_ln)."""
+        ln = (stats, norm): x is the RAW block input and the LayerNorm is folded into the qkv GEMM (ops.linear_ln).
+        keep_t: only the first keep_t temporal tokens are queries -> (S, keep_t, C); residual must have that shape."""
         s, t, c = x.shape
         if ln is not None:
             stats, norm = ln
@@ -62,7 +64,7 @@ class Attention(nn.Module):
             qkv = ops.linear_ln(x, stats, wg, cs, bp, norm.eps)
         else:
             qkv = ops.linear(x, self.qkv.weight, self.qkv.bias)
-        a = ops.temporal_attention(qkv, s, t, c, self.heads, self.scale)
+        a = ops.temporal_attention(qkv, s, t, c, self.heads, self.scale, tq=keep_t)
         return ops.linear(a, self.proj.weight, self.proj.bias, residual=residual), None
 
 
@@ -75,11 +77,23 @@ class Block(nn.Module):
         self.mlp = FeedForward(dim, mlp_dim, dropout)
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
-    def forward(self, x, mask=None, return_attention=False):
+    def forward(self, x, mask=None, return_attention=False, keep_t=None):
+        """keep_t (internal, the LAST global block only): the caller uses temporal tokens 0 .. keep_t-1 of the result alone
+        (mTVE:745 keeps slices 0..2), so queries, projection, residual and MLP run on those tokens only -> (S, keep_t, C).
+        Identical values for the kept tokens; 40 % of the block's proj / MLP work saved at T = 5."""
         if return_attention:
             raise NotImplementedError("attention maps are not materialised")
         if self.training:
             refuse_stochastic_depth(self)
+        if keep_t is not None and keep_t < x.shape[1] and ops.storage() == "fp32":
+            s_, t_, c_ = x.shape
+            xr = torch.empty(s_, keep_t, c_, device=x.device, dtype=torch.float32)
+            ops.copy_rows(x, t_ * c_, xr, keep_t * c_, s_, keep_t * c_)            # the kept tokens of the residual stream, compact
+            st = ops.ln_stats_of(x)
+            ln = (st, self.norm1) if st is not None and ops.linear_ln_tiles(s_ * t_, 3 * c_, c_) > 0 else None
+            xn = x if ln is not None else ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            y, _ = self.attn(xn, mask, residual=xr, ln=ln, keep_t=keep_t)
+            return self.mlp(ops.layernorm(y, self.norm2.weight, self.norm2.bias, self.norm2.eps), residual=y)
         # norm1 folds into the qkv GEMM when the previous block's fc2 left row statistics on x (see SwinTransformerBlock.forward)
         m, c = x.numel() // x.shape[-1], x.shape[-1]
         st = ops.ln_stats_of(x)

@@ -679,10 +679,12 @@ def patch_merge_ln(x, gamma, beta, b, hs, w, c, eps=1e-5):
     return out
 
 
-def temporal_attention(qkv, s, t, c, heads, scale):
+def temporal_attention(qkv, s, t, c, heads, scale, tq=None):
+    """tq: number of leading temporal tokens that are queries (default all): out (s, tq, c)."""
     qkv = _chk(qkv, "qkv")
-    out = torch.empty(s, t, c, device=qkv.device, dtype=torch.float32)
-    _call("mumpy_temporal_attention_fwd", _p(qkv), _p(out), s, t, c, heads, scale, _stream())
+    tq = t if tq is None else tq
+    out = torch.empty(s, tq, c, device=qkv.device, dtype=torch.float32)
+    _call("mumpy_temporal_attention_q_fwd", _p(qkv), _p(out), s, t, tq, c, heads, scale, _stream())
     return out
 
 

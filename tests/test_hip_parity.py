@@ -454,6 +454,25 @@ def test_background_window_attention_is_bit_identical():
         assert torch.equal(got, ref)
 
 
+@pytest.mark.parametrize("s_,t", [(392, 5), (49, 9), (98, 3)])
+def test_last_global_block_computes_only_the_kept_temporal_tokens(s_, t):
+    """Block.forward(x, keep_t=3) -- the last of the 12 global blocks, whose output the encoder tail slices to temporal tokens 0..2
+    (mTVE:745) -- equals Block.forward(x)[:, :3]: every token is still a key / value, but queries, projection, residual and MLP
+    run on the kept tokens only.  Also the query-subset attention kernel itself (mumpy_temporal_attention_q_fwd) against the full one."""
+    from models.modules.blocks import Block
+    blk = fill_module_(Block(768, 12, 3072, 0.0, 0.0), "gk/").eval().to(DEV)
+    x = seeded_randn(80 + t, s_, t, 768).to(DEV)
+    with torch.no_grad():
+        full = blk(x)
+        kept = blk(x, keep_t=3)
+    assert kept.shape == (s_, 3, 768)
+    assert rel_err(kept.cpu(), full[:, :3].cpu()) < 1e-5
+    qkv = seeded_randn(81, s_, t, 3 * 768).to(DEV)
+    a_full = ops.temporal_attention(qkv, s_, t, 768, 12, 64 ** -0.5)
+    a_q = ops.temporal_attention(qkv, s_, t, 768, 12, 64 ** -0.5, tq=min(3, t))
+    assert torch.equal(a_q, a_full[:, :min(3, t)].contiguous())
+
+
 def test_kept_workspace_status_word():
     """The sticky status word of a kept GEMM workspace: zero after split-schedule launches (M = 1960: every tile is cut across
     workgroups), non-zero values are reported by ops.check_workspaces() as an error and the workspaces are re-zeroed."""
