@@ -271,6 +271,13 @@ int mumpy_temporal_attention_fwd(const float* qkv, float* out, int64_t S, int T,
  * keeps temporal slices 0..2 (mTVE:745), so the last global block computes nothing for t >= 3. */
 int mumpy_temporal_attention_q_fwd(const float* qkv, float* out, int64_t S, int T, int Tq, int C, int heads, float scale, void* stream);
 
+/* Attention MAPS for the `return_attention=True` variants (blocks:85-87; deform:364-396; mTVE:134-137) -- a visualisation path:
+ * out (outer, heads, nq, nk) = softmax(scale * q k^T) per (outer, head); q row i of unit (o, h) at q + (o % q_mod) * q_outer_stride +
+ * i * q_row_stride + h * d, k row j at k + o * k_outer_stride + j * k_row_stride + h * d (strides in floats); nq, nk, d <= 64. */
+int mumpy_attention_probs_fwd(const float* q, const float* k, float* out, int64_t outer, int heads, int nq, int nk, int d,
+                              int64_t q_outer_stride, int64_t q_row_stride, int64_t k_outer_stride, int64_t k_row_stride,
+                              int64_t q_mod, float scale, void* stream);
+
 /* ---- Decoder glue in NHWC (decoder.py:67-225): everything between two convolutions ---------------------------
  * gn_stats: x (B,HW,C) NHWC -> partial (B, nsplit, G, 2) = per-slice {sum, sum of squares} of each GroupNorm group
  * (nn.GroupNorm statistics, decoder.py:70,77,84,91,101-119,151-180), combined in fixed order by gn_apply. */

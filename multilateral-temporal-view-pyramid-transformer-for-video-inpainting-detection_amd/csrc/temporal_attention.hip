@@ -154,3 +154,64 @@ extern "C" int mumpy_temporal_attention_q_fwd(const float* qkv, float* out, int6
     MUMPY_CHECK_LAUNCH("temporal_attention");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Attention MAPS (visualisation path only: `return_attention=True` of blocks.Block / SwinDAttention / CVAModule, blocks:85-87,
+// deform:364-396, mTVE:134-137 -- no caller of the forward or training path asks for them, and the fast kernels keep the
+// probabilities in registers).  P = softmax(scale * q k^T) per unit (outer index o, head h): Nq, Nk <= 64, head width D <= 64.
+// One wave per unit, lane = key: the key row sits in registers, a query's scores are one value per lane, max / sum are wave
+// reductions.  q / k are addressed by strides so that the same kernel reads the temporal qkv tensor and the deformable q / kv.
+namespace {
+struct ProbsArgs {
+    const float* q; const float* k; float* out;
+    int64_t units;             // outer * heads
+    int heads, nq, nk, d;
+    int64_t q_outer, q_row, k_outer, k_row;    // strides in floats; head h adds h * d
+    int64_t q_mod;             // q outer index = outer % q_mod (deform:330: kv window i pairs with q window i mod B1)
+    float scale;
+};
+
+__global__ __launch_bounds__(256) void attention_probs_kernel(ProbsArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * 4 + wave;
+    if (u >= a.units) return;
+    const int h = (int)(u % a.heads);
+    const int64_t o = u / a.heads;
+    const float* qb = a.q + (o % a.q_mod) * a.q_outer + (int64_t)h * a.d;
+    const float* kb = a.k + o * a.k_outer + (int64_t)h * a.d;
+    float kr[64];
+    const bool live = lane < a.nk;
+#pragma unroll
+    for (int c = 0; c < 64; ++c) kr[c] = (live && c < a.d) ? kb[(int64_t)lane * a.k_row + c] : 0.f;
+    float* ob = a.out + u * a.nq * a.nk;
+    for (int i = 0; i < a.nq; ++i) {
+        const float* qr = qb + (int64_t)i * a.q_row;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 64; ++c)
+            if (c < a.d) s = fmaf(qr[c], kr[c], s);             // (qr[c] is wave-uniform: scalar loads)
+        s = live ? s * a.scale : -3.0e38f;
+        float m = s;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        const float e = live ? __expf(s - m) : 0.f;
+        const float sum = wave_sum(e, 64);
+        if (live) ob[(int64_t)i * a.nk + lane] = e / sum;
+    }
+}
+}  // namespace
+
+extern "C" int mumpy_attention_probs_fwd(const float* q, const float* k, float* out, int64_t outer, int heads, int nq, int nk, int d,
+                                         int64_t q_outer_stride, int64_t q_row_stride, int64_t k_outer_stride, int64_t k_row_stride,
+                                         int64_t q_mod, float scale, void* stream) {
+    MUMPY_REQUIRE(q && k && out, MUMPY_ENULL, "attention_probs: null pointer");
+    MUMPY_REQUIRE(outer >= 0 && heads > 0 && nq >= 1 && nq <= 64 && nk >= 1 && nk <= 64 && d >= 1 && d <= 64 && q_mod >= 1, MUMPY_EINVAL,
+                  "attention_probs: need 1 <= nq, nk, d <= 64 (got %d, %d, %d)", nq, nk, d);
+    if (outer == 0) return 0;
+    ProbsArgs a{q, k, out, outer * heads, heads, nq, nk, d, q_outer_stride, q_row_stride, k_outer_stride, k_row_stride, q_mod, scale};
+    const int64_t grid = (a.units + 3) / 4;
+    MUMPY_REQUIRE(grid < (1ll << 31), MUMPY_ERANGE, "attention_probs: too many units");
+    hipLaunchKernelGGL(attention_probs_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), a);
+    MUMPY_CHECK_LAUNCH("attention_probs");
+    return 0;
+}

@@ -28,7 +28,10 @@ class CVAModule(nn.Module):
         self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
 
     def forward(self, x1, x2, mask=None, return_attention=False):
-        """Reference signature (mTVE:134-139): windows in, (x1 + y, None) out."""
+        """Reference signature (mTVE:134-139): windows in, (x1 + y, attn-or-None) out; return_attention=True returns the maps
+        (B1, r*nH, 49, 49) alone, as the reference does."""
+        if return_attention:
+            return self.crossattn(x1, x2, return_attention=True)[1]
         y, _ = self.crossattn(x1, x2)
         return ops.add(x1, y), None
 

@@ -81,8 +81,11 @@ class Block(nn.Module):
         """keep_t (internal, the LAST global block only): the caller uses temporal tokens 0 .. keep_t-1 of the result alone
         (mTVE:745 keeps slices 0..2), so queries, projection, residual and MLP run on those tokens only -> (S, keep_t, C).
         Identical values for the kept tokens; 40 % of the block's proj / MLP work saved at T = 5."""
-        if return_attention:
-            raise NotImplementedError("attention maps are not materialised")
+        if return_attention:          # blocks:85-87: the (S, heads, T, T) map of this block's attention, nothing else
+            s_, t_, c_ = x.shape
+            qkv = ops.linear(ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps), self.attn.qkv.weight, self.attn.qkv.bias)
+            return ops.attention_probs(qkv, qkv[..., c_:], s_, self.attn.heads, t_, t_, c_ // self.attn.heads,
+                                       (t_ * 3 * c_, 3 * c_), (t_ * 3 * c_, 3 * c_), self.attn.scale)
         if self.training:
             refuse_stochastic_depth(self)
         if keep_t is not None and keep_t < x.shape[1] and ops.storage() == "fp32":

@@ -86,8 +86,10 @@ class SwinDAttention(nn.Module):
         o = self._attend(x1, x2, q_grid, kv_grid, prep)
         return ops.linear(o, self.proj_out.weight, self.proj_out.bias)
 
-    def _attend(self, x1, x2, q_grid, kv_grid, prep=None):
-        """Everything up to (not including) proj_out: -> o (nq,49,C), the attention output summed over the r-tuples."""
+    def _attend(self, x1, x2, q_grid, kv_grid, prep=None, want_maps=False):
+        """Everything up to (not including) proj_out: -> o (nq,49,C), the attention output summed over the r-tuples.
+        want_maps: also return the attention maps (nq, r*nH, 49, 49) the reference hands back (deform:396) -- a visualisation path
+        (the fast kernel keeps the probabilities in registers; a small separate kernel recomputes them from q and k)."""
         c = self.nc
         b, h, w = q_grid
         b2, hs2, w2 = kv_grid
@@ -105,7 +107,13 @@ class SwinDAttention(nn.Module):
             sampled = ops.deform_sample(x2, pos, b2, hs2, w2, c, nq)
             kv = ops.linear(sampled, wkv, bkv)                                    # (nkv,49,2C)
         pad = self._pad.get((self.proj_q.weight,), lambda: ops.pad_mask().to(x1.device))
-        return ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)   # (nq,49,C)
+        o = ops.deform_attention(q, kv, pad, b, h, w, c, nkv // nq, self.scale)      # (nq,49,C)
+        if not want_maps:
+            return o
+        # kv window i pairs with q window i mod nq; q is raster (b, h*w, C): gather its windows first (49 x C each)
+        qw = q.view(b, h // 7, 7, w // 7, 7, c).permute(0, 1, 3, 2, 4, 5).reshape(nq, 49, c).contiguous()
+        maps = ops.attention_probs(qw, kv, nkv, self.n_heads, 49, 49, 32, (49 * c, c), (49 * 2 * c, 2 * c), self.scale, q_mod=nq)
+        return o, maps.reshape(nq, (nkv // nq) * self.n_heads, 49, 49)                # '(B nH) n m -> B (r nH) n m' (deform:396)
 
     def attend_combine(self, x1, x2, b, h, w, hs2, prep=None):
         """The cross block's use of the module (mTVE:283-286): x1 + x1[window order] + the scrambled attention output, i.e.
@@ -125,8 +133,10 @@ class SwinDAttention(nn.Module):
     def forward(self, x1, x2, return_attention=False):
         """Reference signature (deform:324): x1 (B1,49,C) q windows, x2 (B2,49,C) kv windows, B2 = r*B1.
         Every window is its own 7x7 image for the kernels.  Returns (y (B1,49,C), None)."""
-        if return_attention:
-            raise NotImplementedError("the attention map is never materialised (its caller discards it, mTVE:284)")
         b1, b2, c = x1.shape[0], x2.shape[0], x1.shape[2]
+        if return_attention:      # the reference returns (x, attn) always (deform:405); here the maps cost a launch, so on request
+            o, maps = self._attend(x1, x2, (b1, 7, 7), (b2, 7, 7), want_maps=True)
+            yt = ops.linear(o, self.proj_out.weight, self.proj_out.bias)
+            return yt.transpose(1, 2).reshape(b1, 49, c), maps
         yt = self._run(x1, x2, (b1, 7, 7), (b2, 7, 7))
         return yt.transpose(1, 2).reshape(b1, 49, c), None       # flat (C,49) re-read as (49,C) (deform:403)

@@ -52,6 +52,7 @@ SIGNATURES = {
     "mumpy_patch_embed_fwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_patch_merge_ln_fwd": [c_f, c_f, c_f, c_f, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_temporal_attention_fwd": [c_f, c_f, c_l, c_i, c_i, c_i, c_fl, c_f],
+    "mumpy_attention_probs_fwd": [c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_l, c_l, c_l, c_l, c_l, c_fl, c_f],
     "mumpy_temporal_attention_q_fwd": [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_fl, c_f],
     "mumpy_sigmoid_threshold_fwd": [c_f, c_f, c_l, c_fl, c_f],
     "mumpy_add_fwd": [c_f, c_f, c_f, c_l, c_f],

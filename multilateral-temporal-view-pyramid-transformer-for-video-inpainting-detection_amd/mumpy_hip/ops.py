@@ -688,6 +688,18 @@ def temporal_attention(qkv, s, t, c, heads, scale, tq=None):
     return out
 
 
+def attention_probs(q, k, outer, heads, nq, nk, d, q_strides, k_strides, scale, q_mod=None):
+    """softmax(scale * q k^T) maps (outer, heads, nq, nk) for the `return_attention=True` variants; q_strides / k_strides =
+    (outer stride, row stride) in floats, head h adds h * d; q_mod: q outer index = outer % q_mod."""
+    for t in (q, k):                      # views into a larger tensor are fine: addressing is by the strides given (no copy)
+        if not t.is_cuda or t.dtype != torch.float32:
+            raise RuntimeError("mumpy_hip: attention_probs needs float32 GPU tensors (there is no CPU path)")
+    out = torch.empty(outer, heads, nq, nk, device=q.device, dtype=torch.float32)
+    _call("mumpy_attention_probs_fwd", q.data_ptr(), k.data_ptr(), _p(out), outer, heads, nq, nk, d, q_strides[0], q_strides[1], k_strides[0],
+          k_strides[1], outer if q_mod is None else q_mod, scale, _stream())
+    return out
+
+
 def sigmoid_threshold(logits, thr=0.5):
     logits = _chk(logits, "logits")
     mask = torch.empty(logits.shape, device=logits.device, dtype=torch.uint8)

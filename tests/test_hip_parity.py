@@ -473,6 +473,43 @@ def test_last_global_block_computes_only_the_kept_temporal_tokens(s_, t):
     assert torch.equal(a_q, a_full[:, :min(3, t)].contiguous())
 
 
+def test_return_attention_variants():
+    """`return_attention=True` of blocks.Block (blocks:85-87), SwinDAttention and CVAModule (deform:364-396,405; mTVE:134-137): the
+    attention maps, recomputed by a small separate kernel from the same q / k the fast kernels use -- checked against softmax of
+    float64 products of those q / k, against the reference's layout (kv window i pairs with q window i mod B1; '(B nH) -> B (r nH)'),
+    and for consistency with the regular forward (rows sum to 1; maps @ v reproduces the attention output)."""
+    from models.encoder.multiTemporalViewEncoder import CVAModule
+    from models.modules.blocks import Block
+    blk = fill_module_(Block(768, 12, 3072, 0.0, 0.0), "ra/").eval().to(DEV)
+    x = seeded_randn(95, 49, 5, 768).to(DEV)
+    with torch.no_grad():
+        maps = blk(x, return_attention=True)
+        qkv = ops.linear(ops.layernorm(x, blk.norm1.weight, blk.norm1.bias), blk.attn.qkv.weight, blk.attn.qkv.bias).cpu().double()
+    assert maps.shape == (49, 12, 5, 5)
+    q, k = (qkv[..., i * 768:(i + 1) * 768].reshape(49, 5, 12, 64).permute(0, 2, 1, 3) for i in (0, 1))
+    ref = torch.softmax(q @ k.transpose(-1, -2) * 64 ** -0.5, -1)
+    assert rel_err(maps.cpu(), ref) < 1e-5
+    cva = fill_module_(CVAModule(96, 3), "rc/").eval().to(DEV)
+    x1, x2 = seeded_randn(96, 4, 49, 96).to(DEV), seeded_randn(97, 12, 49, 96).to(DEV)            # r = 3
+    with torch.no_grad():
+        attn = cva(x1, x2, return_attention=True)
+        y, attn2 = cva.crossattn(x1, x2, return_attention=True)
+        y0, none = cva.crossattn(x1, x2)
+    assert attn.shape == (4, 9, 49, 49) and torch.equal(attn, attn2) and none is None
+    assert rel_err(y.cpu(), y0.cpu()) < 1e-6
+    assert float((attn.sum(-1) - 1).abs().max()) < 1e-5
+    # against float64 from the module's own q / kv tensors: q window = kv window mod 4 (x1.repeat, deform:330)
+    att = cva.crossattn
+    with torch.no_grad():
+        qd, pos = att._prep(x1, (4, 7, 7))
+        wkv = torch.cat([att.proj_k.weight.reshape(96, 96), att.proj_v.weight.reshape(96, 96)], 0)
+        kvd = ops.linear(ops.deform_sample(x2, pos, 12, 7, 7, 96, 4), wkv, torch.cat([att.proj_k.bias, att.proj_v.bias]))
+    qh = qd.cpu().double().reshape(4, 49, 3, 32).permute(0, 2, 1, 3)
+    kh = kvd.cpu().double()[..., :96].reshape(12, 49, 3, 32).permute(0, 2, 1, 3)
+    ref = torch.softmax(qh[torch.arange(12) % 4] @ kh.transpose(-1, -2) * 32 ** -0.5, -1).reshape(4, 9, 49, 49)
+    assert rel_err(attn.cpu(), ref) < 1e-5
+
+
 def test_kept_workspace_status_word():
     """The sticky status word of a kept GEMM workspace: zero after split-schedule launches (M = 1960: every tile is cut across
     workgroups), non-zero values are reported by ops.check_workspaces() as an error and the workspaces are re-zeroed."""
