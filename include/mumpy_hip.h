@@ -393,6 +393,15 @@ int64_t mumpy_linear_bwd_workspace_bytes(int64_t M, int N, int K);
 int mumpy_linear_bwd(const float* x, const float* W, const float* dy, float* dx, float* dW, float* db, int64_t M, int N, int K,
                      int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* PatchMerging's 2x2 gather (reference swin_transformer PatchMerging.forward, swin:357-361) and its inverse as one permutation:
+ * merged (B,H/2,W/2,4C), channel block q from pixel (2i + (q&1), 2j + (q>>1)) of x (B,H,W,C).  inverse != 0: `in` is the merged
+ * layout and `out` the (B,H,W,C) one (the gather's backward).  H, W even, C % 4 == 0. */
+int mumpy_patch_gather_fwd(const float* in, float* out, int64_t B, int H, int W, int C, int inverse, void* stream);
+
+/* Weight of the data-gradient convolution: out (Cin,kh,kw,Cout), out[ci][r][s][co] = w_krsc[co][kh-1-r][kw-1-s][ci] -- dX of
+ * mumpy_conv2d_nhwc_fwd is mumpy_conv2d_nhwc_fwd(dY, this) (one launch instead of torch's permute + flip + contiguous). */
+int mumpy_conv_weight_dgrad_fwd(const float* w_krsc, float* out, int Cout, int Cin, int kh, int kw, void* stream);
+
 /* Weight gradient of mumpy_conv2d_nhwc_fwd (the decoder's nn.Conv2d under loss.backward(), decoder.py:9,24-31,68-95):
  * dW (Cout,kh,kw,Cin) (+)= sum over output pixels p of dy[p][:] (x) x[p + tap displacement][:], taps outside the image
  * contributing zero -- ONE launch over all taps on the NHWC tensors as they are (no padded or shifted copies, no transposes):

@@ -225,6 +225,51 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// PatchMerging's 2x2 gather (swin:357-361) as one permutation kernel, both directions: merged (B, H/2, W/2, 4C) with channel block
+// q = 0..3 taken from pixel (2i + (q & 1), 2j + (q >> 1)) of x (B, H, W, C).  INV scatters a merged-layout tensor back (the
+// backward of the gather: torch's indexing needs 4 x 2 slice_backward = 16 fill/copy launches for it).
+template <bool INV>
+__global__ __launch_bounds__(256) void patch_gather_kernel(const f32x4* __restrict__ in, f32x4* __restrict__ out, int H, int W, int C4,
+                                                           int64_t total) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= total) return;
+    const int c = (int)(m % C4);
+    int64_t r = m / C4;
+    const int q = (int)(r & 3);
+    r >>= 2;
+    const int W2 = W >> 1, H2 = H >> 1;
+    const int j = (int)(r % W2);
+    r /= W2;
+    const int i = (int)(r % H2);
+    const int64_t b = r / H2;
+    const int64_t src = ((b * H + 2 * i + (q & 1)) * W + 2 * j + (q >> 1)) * C4 + c;
+    if (INV) out[src] = in[m];
+    else out[m] = in[src];
+}
+
+// The data-gradient convolution's weight: out (Cin, kh, kw, Cout) with out[ci][r][s][co] = w[co][kh-1-r][kw-1-s][ci] from the
+// KRSC image w (Cout, kh, kw, Cin) -- per tap a strided 64x64-tiled transpose; grid.z = tap.  (torch: permute + flip + contiguous
+// = two launches per convolution backward.)
+__global__ __launch_bounds__(256) void conv_weight_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Cout, int Cin,
+                                                                int taps) {
+    __shared__ float tile[64][65];
+    const int tap = blockIdx.z, src_tap = taps - 1 - tap;          // (kh-1-r) kw + (kw-1-s) = taps - 1 - (r kw + s)
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;          // r: co, c: ci
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int64_t in_pitch = (int64_t)taps * Cin, out_pitch = (int64_t)taps * Cout;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int co = r0 + ty + 4 * i, ci = c0 + tx;
+        if (co < Cout && ci < Cin) tile[ty + 4 * i][tx] = w[co * in_pitch + (int64_t)src_tap * Cin + ci];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int ci = c0 + ty + 4 * i, co = r0 + tx;
+        if (ci < Cin && co < Cout) out[ci * out_pitch + (int64_t)tap * Cout + co] = tile[tx][ty + 4 * i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm (+ReLU) backward on NHWC (BaselineDecoder blocks, decoder.py:233-271).  With xhat = (z - mean_g) rstd_g,
 // pre = xhat gamma_c + beta_c, g = dy * [pre > 0] (ReLU) :
@@ -460,6 +505,32 @@ extern "C" int mumpy_transpose_fwd(const float* in, float* out, int64_t R, int64
     hipLaunchKernelGGL(transpose_kernel, dim3((unsigned)((C + 63) / 64), (unsigned)((R + 63) / 64)), dim3(256), 0, as_stream(stream),
                        in, out, R, C);
     MUMPY_CHECK_LAUNCH("transpose");
+    return 0;
+}
+
+extern "C" int mumpy_patch_gather_fwd(const float* in, float* out, int64_t B, int H, int W, int C, int inverse, void* stream) {
+    if (B == 0) return 0;
+    MUMPY_REQUIRE(in && out, MUMPY_ENULL, "patch_gather: null pointer");
+    MUMPY_REQUIRE(aligned16(in) && aligned16(out), MUMPY_EALIGN, "patch_gather: buffers must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 4 == 0, MUMPY_EINVAL,
+                  "patch_gather: need even H, W and C %% 4 == 0 (got %d x %d x %d)", H, W, C);
+    const int64_t total = B * H * W * (C / 4);
+    MUMPY_REQUIRE((total + 255) / 256 < (1ll << 31), MUMPY_ERANGE, "patch_gather: too many elements");
+    const dim3 grid((unsigned)((total + 255) / 256));
+    if (inverse)
+        hipLaunchKernelGGL(patch_gather_kernel<true>, grid, dim3(256), 0, as_stream(stream), (const f32x4*)in, (f32x4*)out, H, W, C / 4, total);
+    else
+        hipLaunchKernelGGL(patch_gather_kernel<false>, grid, dim3(256), 0, as_stream(stream), (const f32x4*)in, (f32x4*)out, H, W, C / 4, total);
+    MUMPY_CHECK_LAUNCH("patch_gather");
+    return 0;
+}
+
+extern "C" int mumpy_conv_weight_dgrad_fwd(const float* w_krsc, float* out, int Cout, int Cin, int kh, int kw, void* stream) {
+    MUMPY_REQUIRE(w_krsc && out, MUMPY_ENULL, "conv_weight_dgrad: null pointer");
+    MUMPY_REQUIRE(Cout > 0 && Cin > 0 && kh > 0 && kw > 0 && kh * kw < 65536 && (Cout + 63) / 64 < 65536, MUMPY_EINVAL, "conv_weight_dgrad: bad shape");
+    hipLaunchKernelGGL(conv_weight_dgrad_kernel, dim3((unsigned)((Cin + 63) / 64), (unsigned)((Cout + 63) / 64), (unsigned)(kh * kw)), dim3(256), 0,
+                       as_stream(stream), w_krsc, out, Cout, Cin, kh * kw);
+    MUMPY_CHECK_LAUNCH("conv_weight_dgrad");
     return 0;
 }
 

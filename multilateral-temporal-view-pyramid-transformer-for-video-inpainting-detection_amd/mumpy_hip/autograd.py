@@ -31,7 +31,8 @@ def _grad_slot(p):
         return None
     if getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
         return None
-    if g.dtype == torch.float32 and g.is_cuda and g.is_contiguous() and g.shape == p.shape and not g.requires_grad:
+    dense = g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))
+    if g.dtype == torch.float32 and g.is_cuda and dense and g.shape == p.shape and not g.requires_grad:
         return g
     return None
 
@@ -241,14 +242,27 @@ def swin_block_train(block, x):
     return _residual_linear(x, block.drop_path, hmid, block.mlp.fc2.weight, block.mlp.fc2.bias)
 
 
+class PatchGatherFn(torch.autograd.Function):
+    """x (B, H*W, C) -> (B, H/2 * W/2, 4C): the 2x2 gather of PatchMerging, a permutation in one launch each way."""
+    @staticmethod
+    def forward(ctx, x, h, w):
+        b, l, c = x.shape
+        if l != h * w or h % 2 or w % 2:
+            raise RuntimeError(f"PatchMerging: {l} tokens are not an even {h} x {w} grid")
+        ctx.geom = (b, h, w, c)
+        return ops.patch_gather(x.contiguous(), *ctx.geom)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.patch_gather(dy.contiguous(), *ctx.geom, inverse=True), None, None
+
+
 def patch_merging_train(pm, x):
     """PatchMerging.forward (swin:344-367) with a backward: 2x2 gather in the order (0,0),(1,0),(0,1),(1,1) (swin:357-361,
-    a pure permutation: torch indexing), LayerNorm(4C) and the bias-free reduction on the HIP kernels."""
+    a pure permutation), LayerNorm(4C) and the bias-free reduction on the HIP kernels."""
     h, w = pm.input_resolution
-    b, l, c = x.shape
-    g = x.view(b, h, w, c)
-    g = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], dim=-1).reshape(b, l // 4, 4 * c)
-    return LinearFn.apply(LayerNormFn.apply(g.contiguous(), pm.norm.weight, pm.norm.bias, pm.norm.eps), pm.reduction.weight, None)
+    g = PatchGatherFn.apply(x, h, w)
+    return LinearFn.apply(LayerNormFn.apply(g, pm.norm.weight, pm.norm.bias, pm.norm.eps), pm.reduction.weight, None)
 
 
 def baseline_tokenize_train(tok, x):
@@ -294,9 +308,16 @@ class Conv2dFn(torch.autograd.Function):
        db = column sums of dY."""
 
     @staticmethod
-    def forward(ctx, x, w_krsc, bias):
+    def forward(ctx, x, weight, bias):
+        """weight: the nn.Conv2d parameter (Cout,Cin,kh,kw) as it is -- channels_last memory when FlatAdamW owns it, so that its
+        (Cout,kh,kw,Cin) image is a view (no copy per step) and the weight gradient accumulates into the grad slot -- or any
+        tensor of that logical shape."""
+        w_krsc = weight.permute(0, 2, 3, 1)
+        if not w_krsc.is_contiguous():
+            w_krsc = w_krsc.contiguous()
         ctx.save_for_backward(x, w_krsc)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return ops.conv2d_nhwc(x, w_krsc, bias)
 
     @staticmethod
@@ -307,11 +328,16 @@ class Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last)
         dy2 = dy.permute(0, 2, 3, 1).reshape(-1, cout)             # (P, Cout) view of the NHWC memory
         dx = dw = db = None
+        fast = ops.matrix_math() in ("fp32", "bf16") and not LEGACY_LINEAR_BWD
         if ctx.needs_input_grad[0]:
-            dx = ops.conv2d_nhwc(dy, w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
+            dx = ops.conv2d_nhwc(dy, ops.conv_weight_dgrad(w) if fast else w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
         if ctx.needs_input_grad[1]:
-            if ops.matrix_math() in ("fp32", "bf16") and not LEGACY_LINEAR_BWD:
-                dw = ops.conv2d_wgrad(x, dy, kh, kw)               # one launch over all taps, no shifted copies (fp32 or bf16 operands)
+            if fast:                                               # one launch over all taps, no shifted copies (fp32 or bf16 operands)
+                wslot = _grad_slot(ctx.params[0])                  # channels_last 4-D slot: its KRSC image is a contiguous view
+                if wslot is not None and wslot.dim() == 4 and wslot.permute(0, 2, 3, 1).is_contiguous():
+                    ops.conv2d_wgrad(x, dy, kh, kw, dw_out=wslot.permute(0, 2, 3, 1))
+                else:
+                    dw = ops.conv2d_wgrad(x, dy, kh, kw).permute(0, 3, 1, 2)       # logical OIHW for autograd
             else:                                                  # split-precision modes: one forward GEMM per tap on copies
                 dyt = ops.transpose(dy2.contiguous(), 32)          # (Cout, Ppad)
                 xp = torch.nn.functional.pad(x.permute(0, 2, 3, 1), (0, 0, kw // 2, kw // 2, kh // 2, kh // 2))   # (B,H+2,W+2,Cin)
@@ -320,9 +346,13 @@ class Conv2dFn(torch.autograd.Function):
                     for kx in range(kw):
                         xs = xp[:, ky:ky + h, kx:kx + wd, :].reshape(-1, cin).contiguous()
                         taps.append(ops.linear(dyt, ops.transpose(xs, 32)))                          # (Cout, Cin)
-                dw = torch.stack(taps, dim=1).reshape(cout, kh, kw, cin)
+                dw = torch.stack(taps, dim=1).reshape(cout, kh, kw, cin).permute(0, 3, 1, 2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = ops.col_sum(dy2.contiguous())
+            bslot = _grad_slot(ctx.params[1]) if fast else None
+            if bslot is not None:                                  # column sums of dY straight into the slot (no add launch)
+                ops.linear_bwd(None, None, dy2.contiguous(), need_dx=False, need_dw=False, need_db=True, db_out=bslot)
+            else:
+                db = ops.col_sum(dy2.contiguous())
         return dx, dw, db
 
 
@@ -390,7 +420,7 @@ def baseline_decoder_train(dec, x):
     x = x.contiguous(memory_format=torch.channels_last)
     for i in range(5):
         conv, gn = getattr(dec, f"decoder_{i + 1}")[0], getattr(dec, f"decoder_{i + 1}")[1]
-        z = Conv2dFn.apply(x, conv.weight.permute(0, 2, 3, 1).contiguous(), conv.bias)
+        z = Conv2dFn.apply(x, conv.weight, conv.bias)
         a = GroupNormActFn.apply(z, gn.weight, gn.bias, gn.num_groups, gn.eps, ops.ACT_RELU)
         x = UpsampleFn.apply(a, 2, True)
     return FinalConvFn.apply(x, dec.final_out.weight.permute(0, 2, 3, 1).contiguous(), dec.final_out.bias)
@@ -426,12 +456,12 @@ def global_block_train(block, x):
 # ---------------------------------------------------------------------------------------------- pyramid Decoder (row 15)
 def _conv_train(x, conv):
     """nn.Conv2d (stride 1, same padding) through Conv2dFn; Cin is zero-padded to a multiple of 32 (the 9-channel DCT input)."""
-    w = conv.weight.permute(0, 2, 3, 1)                                   # (Cout, kh, kw, Cin)
-    pad = (-w.shape[3]) % 32
-    if pad:
-        w = torch.nn.functional.pad(w, (0, pad))
+    w = conv.weight                                                       # (Cout, Cin, kh, kw)
+    pad = (-w.shape[1]) % 32
+    if pad:                                                               # (a derived tensor: its gradient goes through autograd)
+        w = torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
         x = torch.cat([x, x.new_zeros(x.shape[0], pad, x.shape[2], x.shape[3])], dim=1)
-    return Conv2dFn.apply(x.contiguous(memory_format=torch.channels_last), w.contiguous(), conv.bias)
+    return Conv2dFn.apply(x.contiguous(memory_format=torch.channels_last), w, conv.bias)
 
 
 def _gcm_train(m, x):

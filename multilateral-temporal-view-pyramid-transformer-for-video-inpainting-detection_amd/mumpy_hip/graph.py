@@ -38,7 +38,8 @@ class GraphedForward:
             for _ in range(self._warmup):
                 self._fwd()
         torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        from .streams import quiesce_collectives
+        quiesce_collectives()                                # device idle; RCCL's watchdog has nothing left to poll (streams.py)
         self.graph = torch.cuda.CUDAGraph()
         # capture_error_mode="thread_local": with a process group alive (one rank per GPU) RCCL's watchdog thread polls events
         # while this thread captures; in the default "global" mode such a call from ANOTHER thread invalidates the capture

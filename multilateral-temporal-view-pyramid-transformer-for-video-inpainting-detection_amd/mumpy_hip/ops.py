@@ -847,12 +847,19 @@ def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_d
     """Backward of y = x W^T + b in ONE C-ABI call (mumpy_linear_bwd), no transposed copies: -> (dx, dW, db).
     dw_out / db_out: gradient buffers to ACCUMULATE into (e.g. views of FlatAdamW's flat gradient); the matching return
     value is then None (nothing left for autograd to add)."""
-    x2d, dy2d, weight = _chk(x2d, "x"), _chk(dy2d, "dy"), _chk(weight, "weight")
-    m, k = x2d.shape
-    n = weight.shape[0]
-    if dy2d.shape != (m, n) or weight.shape[1] != k:
-        raise RuntimeError(f"linear_bwd: x {tuple(x2d.shape)}, weight {tuple(weight.shape)}, dy {tuple(dy2d.shape)} do not match")
-    dev = x2d.device
+    dy2d = _chk(dy2d, "dy")
+    if x2d is None and weight is None:                           # bias gradient only (column sums of dY, e.g. a convolution's bias)
+        if need_dx or need_dw or not need_db:
+            raise RuntimeError("linear_bwd: without x and weight only the bias gradient can be asked for")
+        m, n = dy2d.shape
+        k = 32
+    else:
+        x2d, weight = _chk(x2d, "x"), _chk(weight, "weight")
+        m, k = x2d.shape
+        n = weight.shape[0]
+        if dy2d.shape != (m, n) or weight.shape[1] != k:
+            raise RuntimeError(f"linear_bwd: x {tuple(x2d.shape)}, weight {tuple(weight.shape)}, dy {tuple(dy2d.shape)} do not match")
+    dev = dy2d.device
     dx = torch.empty(m, k, device=dev, dtype=torch.float32) if need_dx else None
     acc = 0
     dw = db = None
@@ -878,6 +885,26 @@ def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_d
     _call("mumpy_linear_bwd", _p(x2d), _p(weight), _p(dy2d), _p(dx), _p(dw), _p(db), m, n, k, acc, _p(ws), wsb, _stream(),
           work=2.0 * m * n * k * (int(need_dx) + int(need_dw)))
     return dx, (None if dw_out is not None else dw), (None if db_out is not None else db)
+
+
+def patch_gather(x, b, h, w, c, inverse=False):
+    """PatchMerging's 2x2 gather (swin:357-361): x (b,h,w,c) -> (b, h/2 * w/2, 4c); inverse=True maps a merged-layout tensor back to
+    (b, h*w, c) (the gather's backward) -- one permutation launch either way."""
+    x = _chk(x, "x")
+    if x.numel() != b * h * w * c:
+        raise RuntimeError(f"patch_gather: {tuple(x.shape)} is not {b} x {h} x {w} x {c}")
+    out = torch.empty((b, h * w, c) if inverse else (b, (h // 2) * (w // 2), 4 * c), device=x.device, dtype=torch.float32)
+    _call("mumpy_patch_gather_fwd", _p(x), _p(out), b, h, w, c, int(inverse), _stream(), work=8.0 * x.numel())
+    return out
+
+
+def conv_weight_dgrad(w_krsc):
+    """(Cout,kh,kw,Cin) -> (Cin,kh,kw,Cout) with the taps flipped: the weight of the data-gradient convolution, one launch."""
+    w_krsc = _chk(w_krsc, "weight")
+    cout, kh, kw, cin = w_krsc.shape
+    out = torch.empty(cin, kh, kw, cout, device=w_krsc.device, dtype=torch.float32)
+    _call("mumpy_conv_weight_dgrad_fwd", _p(w_krsc), _p(out), cout, cin, kh, kw, _stream(), work=8.0 * out.numel())
+    return out
 
 
 def conv2d_wgrad(x, dy, kh, kw, dw_out=None):

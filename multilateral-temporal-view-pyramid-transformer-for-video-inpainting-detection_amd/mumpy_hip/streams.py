@@ -36,6 +36,17 @@ def new_distinct_stream(device, avoid=(), priority=0):
     raise RuntimeError("mumpy_hip.streams: torch's stream pool is exhausted (more than 32 concurrent side streams)")
 
 
+def quiesce_collectives():
+    """Call before a hipGraph capture: device idle, and -- with an RCCL process group alive -- its watchdog thread given time to
+    retire every finished collective (it sweeps its list every 100 ms).  A collective still on that list while a capture is open
+    is polled through hipEventQuery from the watchdog thread, which on ROCm 7.2 can fail with hipErrorCapturedEvent and abort the
+    process (tools/rccl_capture_probe.py); an empty list cannot."""
+    torch.cuda.synchronize()
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_backend() == "nccl":
+        import time
+        time.sleep(0.5)
+
+
 def _side_stream(device, i, parent=None):
     # keyed by the PARENT stream as well: two forks at the same depth under different parents never share a side stream
     key = (str(device), _DEPTH[0], i, None if parent is None else parent.cuda_stream)

@@ -66,15 +66,26 @@ class FlatAdamW:
         self.exp_avg = torch.zeros(n, device=dev, dtype=torch.float32)
         self.exp_avg_sq = torch.zeros(n, device=dev, dtype=torch.float32)
         for p, o in zip(self.params, self.offsets):
-            view = self.param[o:o + p.numel()].view_as(p)
+            view = self._slot(self.param, p, o)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.grad[o:o + p.numel()].view_as(p)
+            p.grad = self._slot(self.grad, p, o)
             p._mumpy_flat_grad = p.grad           # marker: the backward kernels may accumulate into this view (autograd._grad_slot)
         self.base_lr = self.lr = lr
         self.weight_decay, self.betas, self.eps = weight_decay, betas, eps
         self.steps = 0            # optimizer steps taken
         self.sched_it = 0         # scheduler steps taken (PolynomialLR.last_epoch)
+
+    @staticmethod
+    def _slot(buf, p, o):
+        """The view of flat buffer `buf` that has p's logical shape.  Spatial nn.Conv2d weights (Cout,Cin,kh,kw) are stored in
+        channels_last order: the (Cout,kh,kw,Cin) image the implicit-GEMM kernels read is then a VIEW of the parameter (no permuted
+        copy per step) and the weight-gradient kernel accumulates straight into the matching view of the gradient.  Logical shapes,
+        state_dict keys / shapes / dtypes are unchanged."""
+        if p.dim() == 4 and p.shape[1] > 1 and p.shape[2] * p.shape[3] > 1:
+            co, ci, kh, kw = p.shape
+            return buf[o:o + p.numel()].view(co, kh, kw, ci).permute(0, 3, 1, 2)
+        return buf[o:o + p.numel()].view(p.shape)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -86,8 +97,8 @@ class FlatAdamW:
         state = {}
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             n = p.numel()
-            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self.exp_avg[o:o + n].view_as(p).detach().clone(),
-                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).detach().clone()}
+            state[i] = {"step": torch.tensor(float(self.steps)), "exp_avg": self._slot(self.exp_avg, p, o).detach().contiguous().clone(),
+                        "exp_avg_sq": self._slot(self.exp_avg_sq, p, o).detach().contiguous().clone()}
         group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "params": list(range(len(self.params)))}
@@ -108,8 +119,8 @@ class FlatAdamW:
                 continue
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError(f"FlatAdamW.load_state_dict: parameter {i} has shape {tuple(p.shape)}, state {tuple(st['exp_avg'].shape)}")
-            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
-            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            self._slot(self.exp_avg, p, o).copy_(st["exp_avg"])
+            self._slot(self.exp_avg_sq, p, o).copy_(st["exp_avg_sq"])
             steps = max(steps, int(float(st["step"])))
         extra = sd.get("mumpy", {})
         self.steps = int(extra.get("steps", steps))          # (one step count per group: every parameter steps together here)
@@ -203,15 +214,28 @@ class GraphedTrainStep:
 
         from .streams import new_distinct_stream
         side = new_distinct_stream(self.x.device, (torch.cuda.current_stream().cuda_stream,))
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):                      # warm-up steps are real steps (caches, allocator, lazy inits)
+        main = torch.cuda.current_stream()
+        side.wait_stream(main)
+        for _ in range(warmup):                          # warm-up steps are real steps (caches, allocator, lazy inits)
+            with torch.cuda.stream(side):
                 fwd_bwd()
-                for o in self.opts:
-                    o.stage_hyper(o.all_reduce_grads() if all_reduce else 1.0)
+            scales = [1.0] * len(self.opts)
+            if all_reduce:
+                # The collectives are issued from the CALLER's stream, never from the stream that captures: ProcessGroupNCCL's
+                # watchdog thread polls the end event of every pending collective, and on ROCm 7.2 that query fails with
+                # hipErrorCapturedEvent (process abort) when the stream the collective was issued from has meanwhile begun a
+                # capture -- reproduced in isolation by tools/rccl_capture_probe.py (issued from the capture stream: abort;
+                # from another stream, or with the watchdog drained first: fine).
+                main.wait_stream(side)
+                scales = [o.all_reduce_grads() for o in self.opts]
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                for o, sc in zip(self.opts, scales):
+                    o.stage_hyper(sc)
                 update()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        main.wait_stream(side)
+        from .streams import quiesce_collectives
+        quiesce_collectives()
         for o in self.opts:
             o.stage_hyper(advance=False)                 # capture records the launches; it does not run a step
         self.graph = torch.cuda.CUDAGraph()

@@ -310,8 +310,55 @@ def test_hip_conv3x3_backward(b, h, w, cin, cout):
     F.conv2d(xr, wr, br, padding=1).backward(dy)
     xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     wg, bg = wt.cuda().requires_grad_(True), bs.cuda().requires_grad_(True)
-    Conv2dFn.apply(xg, wg.permute(0, 2, 3, 1).contiguous(), bg).backward(dy.cuda())
+    Conv2dFn.apply(xg, wg, bg).backward(dy.cuda())
     assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5 and rel_err(wg.grad.cpu(), wr.grad) < 2e-5 and rel_err(bg.grad.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w,c", [(2, 56, 56, 96), (3, 14, 70, 512), (1, 2, 2, 4)])
+def test_hip_patch_gather_both_ways(b, h, w, c):
+    """PatchMerging's 2x2 gather against the reference's indexing (swin:357-361), and its inverse: bit-exact (permutations)."""
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import PatchGatherFn
+    x = seeded_randn(43, b, h * w, c)
+    g = x.view(b, h, w, c)
+    want = torch.cat([g[:, 0::2, 0::2], g[:, 1::2, 0::2], g[:, 0::2, 1::2], g[:, 1::2, 1::2]], dim=-1).reshape(b, -1, 4 * c)
+    xg = x.cuda().requires_grad_(True)
+    got = PatchGatherFn.apply(xg, h, w)
+    assert torch.equal(got.detach().cpu(), want)
+    assert torch.equal(ops.patch_gather(got.detach(), b, h, w, c, inverse=True).cpu(), x)
+    dy = seeded_randn(44, *want.shape)
+    got.backward(dy.cuda())
+    xr = x.clone().requires_grad_(True)
+    gr = xr.view(b, h, w, c)
+    torch.cat([gr[:, 0::2, 0::2], gr[:, 1::2, 0::2], gr[:, 0::2, 1::2], gr[:, 1::2, 1::2]], dim=-1).reshape(b, -1, 4 * c).backward(dy)
+    assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+@pytest.mark.gpu
+def test_hip_conv_weight_dgrad_and_channels_last_slots():
+    """The one-launch data-gradient weight against torch's permute + flip (bit-exact: a copy), and Conv2dFn on a FlatAdamW-owned
+    conv: channels_last parameter storage (its KRSC image is a view), weight / bias gradients ACCUMULATED into the flat slots."""
+    from mumpy_hip import ops
+    from mumpy_hip.autograd import Conv2dFn
+    from mumpy_hip.train import FlatAdamW
+    for cout, cin, kh, kw in [(32, 64, 3, 3), (96, 40, 3, 3), (64, 64, 1, 1), (7, 130, 5, 3)]:
+        w = seeded_randn(40, cout, kh, kw, cin).cuda()
+        assert torch.equal(ops.conv_weight_dgrad(w), w.permute(3, 1, 2, 0).flip(1, 2).contiguous())
+    conv = torch.nn.Conv2d(64, 32, 3, padding=1)
+    fill_module_(conv)
+    ref = torch.nn.Conv2d(64, 32, 3, padding=1)
+    ref.load_state_dict(conv.state_dict())
+    conv = conv.cuda()
+    opt = FlatAdamW(list(conv.parameters()), lr=1e-3)
+    assert conv.weight.shape == (32, 64, 3, 3) and conv.weight.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(conv.state_dict()["weight"].cpu(), ref.weight.detach())
+    x, dy = seeded_randn(41, 2, 64, 14, 14), seeded_randn(42, 2, 32, 14, 14)
+    for _ in range(2):                                             # two backward passes accumulate
+        ref(x).backward(dy)
+        Conv2dFn.apply(x.cuda().contiguous(memory_format=torch.channels_last), conv.weight, conv.bias).backward(dy.cuda())
+    assert conv.weight.grad.data_ptr() == opt.grad.data_ptr() or conv.bias.grad.data_ptr() == opt.grad.data_ptr()
+    assert rel_err(conv.weight.grad.cpu(), ref.weight.grad) < 2e-5 and rel_err(conv.bias.grad.cpu(), ref.bias.grad) < 2e-5
 
 
 @pytest.mark.gpu

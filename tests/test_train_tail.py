@@ -226,6 +226,35 @@ def test_flat_adamw_state_dict_is_torch_adamw_layout(tmp_path):
     assert (fresh.steps, fresh.sched_it, fresh.base_lr) == (11, 9, 2e-3)
 
 
+def test_flat_adamw_conv_weights_are_channels_last_views():
+    """CPU: a spatial conv weight adopted by FlatAdamW keeps its logical (Cout,Cin,kh,kw) shape and values, but its memory (and
+    its gradient's and the Adam moments') is the (Cout,kh,kw,Cin) image the HIP convolution reads; the optimizer state still
+    round-trips through torch.optim.AdamW in logical order."""
+    from mumpy_hip.train import FlatAdamW
+    torch.manual_seed(6)
+    net = torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.Conv2d(6, 2, 1), torch.nn.Conv2d(1, 3, 3))
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    opt = FlatAdamW(net.parameters(), lr=1e-3)
+    w = net[0].weight
+    assert w.shape == (6, 4, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous() and w.grad.permute(0, 2, 3, 1).is_contiguous()
+    assert w.data_ptr() == opt.param.data_ptr() and net[1].weight.is_contiguous() and net[2].weight.is_contiguous()
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())
+    assert torch.equal(opt.param[:w.numel()].view(6, 3, 3, 4), before["0.weight"].permute(0, 2, 3, 1))
+    net[0](torch.randn(2, 4, 5, 5)).square().sum().backward()    # autograd accumulates into the permuted views as well
+    assert opt.grad[:w.numel()].abs().sum() > 0
+    opt.exp_avg.normal_(); opt.exp_avg_sq.uniform_()
+    sd = opt.state_dict()
+    assert sd["state"][0]["exp_avg"].shape == (6, 4, 3, 3) and sd["state"][0]["exp_avg"].is_contiguous()
+    assert torch.equal(sd["state"][0]["exp_avg"].permute(0, 2, 3, 1).reshape(-1), opt.exp_avg[:w.numel()])
+    twin = torch.optim.AdamW(net.parameters(), lr=1.0)
+    twin.load_state_dict({k: v for k, v in sd.items() if k != "mumpy"})
+    fresh = FlatAdamW(torch.nn.Sequential(torch.nn.Conv2d(4, 6, 3, padding=1), torch.nn.Conv2d(6, 2, 1), torch.nn.Conv2d(1, 3, 3)).parameters(), lr=1.0)
+    fresh.load_state_dict(twin.state_dict())
+    for i, (p, o) in enumerate(zip(opt.params, opt.offsets)):
+        assert torch.equal(fresh.exp_avg[o:o + p.numel()], opt.exp_avg[o:o + p.numel()])
+        assert torch.equal(fresh.exp_avg_sq[o:o + p.numel()], opt.exp_avg_sq[o:o + p.numel()])
+
+
 @pytest.mark.gpu
 def test_checkpoint_resume_continues_the_same_trajectory(tmp_path):
     """save -> load -> continue == never having stopped: parameters, both moments, step and scheduler counters survive

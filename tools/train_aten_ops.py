@@ -49,6 +49,6 @@ by_op = collections.Counter()
 for (n, sh), c in rows.items():
     by_op[n] += c
 print("by op:", dict(by_op.most_common()))
-for (n, sh), c in rows.most_common(45):
+for (n, sh), c in rows.most_common(int(os.environ.get("TOP", "45"))):
     print(f"{c:5d} {n:22s} {sh}")
 print("C-ABI calls:", {k: len(v) for k, v in sorted(ours.items(), key=lambda kv: -len(kv[1]))})
