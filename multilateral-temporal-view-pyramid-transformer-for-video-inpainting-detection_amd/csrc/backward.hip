@@ -55,9 +55,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < RU; ++u) s[u] += __shfl_xor(s[u], o);
+        for (int u = 0; u < RU; ++u) s[u] = wave_sum(s[u], 64);               // DPP butterfly (common.h): RU independent chains
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const float mean = s[u] * invc;
@@ -72,9 +70,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < RU; ++u) q[u] += __shfl_xor(q[u], o);
+        for (int u = 0; u < RU; ++u) q[u] = wave_sum(q[u], 64);
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             const float rstd = rsqrtf(q[u] * invc + eps);
@@ -91,9 +87,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         }
 #pragma unroll
-        for (int o = 32; o >= 1; o >>= 1)
-#pragma unroll
-            for (int u = 0; u < RU; ++u) { sg[u] += __shfl_xor(sg[u], o); sgx[u] += __shfl_xor(sgx[u], o); }
+        for (int u = 0; u < RU; ++u) { sg[u] = wave_sum(sg[u], 64); sgx[u] = wave_sum(sgx[u], 64); }
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             if (rb + u >= r1) continue;
