@@ -51,6 +51,9 @@ constexpr int PASSES = BM / 8;              // epilogue passes per tile: 8 rows 
 #define MUMPY_WS_DBG 0      // harness diagnostics, compile time (a runtime switch would put branches around the loads): 1 = no operand loads, 2 = no epilogue, 4 = no LDS staging writes, 8 = no priority
 #endif
 constexpr int DBG = MUMPY_WS_DBG;
+#ifndef MUMPY_WS_STORE_AUX
+#define MUMPY_WS_STORE_AUX 0   // cache policy bits of the output stores (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#endif
 constexpr uint32_t OOB = 0x80000000u;       // buffer offset past every buffer: the access is dropped by the bounds check
 constexpr int LN_GUARD_WORD = 1022;         // sticky: a folded LayerNorm met a row with |mean| > LN_GUARD_RATIO sigma (reduced accuracy)
 constexpr float LN_GUARD_RATIO = 256.f;
@@ -70,6 +73,7 @@ struct Params {
     unsigned tiles;        // gm * gn
     unsigned rr_cnt, rr_G; // whole-tile schedule: tiles per workgroup (max) and grid size; 0 = split schedule (virtual id = position)
     unsigned st_w;         // super-tile width in tiles (4, 2 or 1)
+    unsigned walk;         // whole-tile schedule, 8 x 32 workgroups: an XCD walks ALONG N inside one strip of SH tile rows (see tile_coords)
     unsigned units;        // tiles * nk: the workgroups split this chunk sequence evenly (split tiles: "stream-K")
     int lmin;              // shortest allowed head part of a split tile (chunks)
     // implicit-GEMM convolution (loader_role<true>): x is an NHWC image batch, row m = output pixel (img, y, x), K index =
@@ -115,7 +119,13 @@ __device__ __forceinline__ void tile_coords(const Params& p, unsigned v, unsigne
     }
     const unsigned SW = p.st_w, SH = 32u / SW, SN = p.gn / SW, row_tiles = SN * 32u;
     const unsigned full_rows = p.gm / SH, full = full_rows * row_tiles;
-    if (q < full) {
+    if (p.walk && q < (full_rows >> 3) * 8u * row_tiles) {
+        // groups of 8 strips (one per XCD): in round r the 32 workgroups of XCD x hold super-tile (strip 8 g + x, column group r),
+        // so the strip's SH x row panels are re-used from the XCD's L2 round after round and only W streams
+        const unsigned grp = 8u * row_tiles, g = q / grp, l = q - g * grp, s = l >> 5, j = l & 31u;
+        tm = (g * 8u + (s & 7u)) * SH + j / SW;
+        tn = (s >> 3) * SW + j % SW;
+    } else if (q < full) {
         const unsigned sm = q / row_tiles, r = q - sm * row_tiles, sn = r >> 5, j = r & 31u;
         tm = sm * SH + j / SW;
         tn = sn * SW + j % SW;
@@ -562,9 +572,9 @@ __device__ __forceinline__ void epilogue_role(const Params& p, float* lds, unsig
             typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
             typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
             const bf16x4 o = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // round to nearest even
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, yo[e], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o), rs_y, yo[e], 0, MUMPY_WS_STORE_AUX);
         } else {
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, yo[e], 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_y, yo[e], 0, MUMPY_WS_STORE_AUX);
         }
     };
     const uint32_t soff = ((uint32_t)e_row * BN + 4u * e_c4) * 4u;
@@ -798,6 +808,7 @@ inline int launch(const float* x, const float* W, const float* bias, const float
     p.st_w = (p.gn % 4 == 0) ? 4u : (p.gn % 2 == 0) ? 2u : 1u;
     p.rr_G = grid;
     p.rr_cnt = (p.tiles + grid - 1) / grid;
+    p.walk = (grid == 256u && !split && tune_int("MUMPY_WS_WALK", 0)) ? 1u : 0u;
     p.flags = nullptr; p.slabs = nullptr;
     if (split) {
         p.rr_cnt = 0;
@@ -882,6 +893,7 @@ inline int launch16(const void* x16, const void* W16, const float* bias, const f
     p.st_w = (p.gn % 4 == 0) ? 4u : (p.gn % 2 == 0) ? 2u : 1u;
     p.rr_G = grid;
     p.rr_cnt = (p.tiles + grid - 1) / grid;
+    p.walk = 0u;
     p.flags = nullptr; p.slabs = nullptr;
 #define MUMPY_WS_LAUNCH16(P_, IO_)                                                                                      \
     do {                                                                                                                \
