@@ -23,10 +23,10 @@ def new_distinct_stream(device, avoid=(), priority=0):
     stream.  Streams drawn and rejected here are dropped again (they are pool members, nothing is destroyed)."""
     taken = {int(h) for h in avoid} | {s.cuda_stream for s in _SIDE.values()}
     # With a process group alive, stay out of the pool RCCL's own stream comes from (ProcessGroupNCCL draws a NORMAL-priority pool
-    # stream): a capture stream that aliases it made the watchdog thread query a collective's end event "last recorded in a
-    # capturing stream" -- hipErrorCapturedEvent, capture invalidated, process aborted (found by the one-rank RCCL rehearsal of
-    # tools/train_ddp_bench.py --graph, round 3).  All of this module's streams then come from the high-priority pool (equal among
-    # themselves, so the fork/join schedule is unchanged).
+    # stream): a capture stream must never be a stream a pending collective is tied to -- the watchdog thread's poll of that
+    # collective's end event then fails with hipErrorCapturedEvent and aborts the process (see quiesce_collectives below and
+    # tools/rccl_capture_probe.py).  All of this module's streams then come from the high-priority pool (equal among themselves,
+    # so the fork/join schedule is unchanged).
     if priority == 0 and torch.distributed.is_available() and torch.distributed.is_initialized():
         priority = -1
     for _ in range(64):
