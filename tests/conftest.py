@@ -13,6 +13,11 @@ for p in (ROOT, GOLDEN, PKG):
         sys.path.insert(0, p)
 
 
+# the oracle (CPU torch) is the slow half of every whole-model test: a GPU box reports all the host's cores while a job owns a share
+# of them, and torch's default of one thread per reported core oversubscribes that share
+torch.set_num_threads(max(1, min(16, os.cpu_count() or 8)))
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

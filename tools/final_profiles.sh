@@ -2,6 +2,7 @@
 # Round-end measurement pass (on the GPU box): smoke, default bench line, T=9 / B=16 lines, rocprofv3 kernel stats (serial and fork/join
 # schedules, fp32 and bf16 storage), timeline gaps of the replayed graph, PMC traffic passes, phase timeline, GEMM shape table,
 # config-5 training lines.  Outputs under gpurun_out/ (tag them into profiles/ with tools/collect_profiles.py).
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R

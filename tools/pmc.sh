@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage: tools/pmc.sh <outdir-under-gpurun_out> <counters...> -- <kernel_micro args...>   (run on the GPU box)
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage (on the GPU box): bash tools/pmc_bench.sh   -> gpurun_out/pmc_bench_{FETCH_SIZE,WRITE_SIZE}/ (one counter per pass)
 # HBM-side traffic of every kernel of the bench workload (eager, serial schedule, 2 timed steps).
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp

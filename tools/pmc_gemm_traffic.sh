@@ -1,5 +1,6 @@
 #!/bin/bash
 # FETCH_SIZE / WRITE_SIZE of the persistent GEMM per SHAPE (one counter per pass), to see which shapes over-fetch.
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 shapes=("fc1 7840 2048 512 1" "fc2 7840 512 2048 0" "qkv 7840 1536 512 0" "proj 7840 512 512 0" "gfc1 1960 3072 768 1" "gfc2 1960 768 3072 0" "s0fc1 125440 512 128 1" "s3fc2 1960 1024 4096 0")

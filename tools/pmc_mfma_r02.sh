@@ -1,5 +1,6 @@
 #!/bin/bash
 # MFMA-busy counter passes (one counter per pass) for the persistent GEMM and window attention on the round's final code
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 for c in SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE; do

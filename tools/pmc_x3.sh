@@ -1,5 +1,6 @@
 #!/bin/bash
 # PMC passes over the split-precision GEMM (one small counter group per pass): bash tools/pmc_x3.sh M N K
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 export TMPDIR=/tmp MUMPY_MATH=${MUMPY_MATH:-bf16x3} REPS=5
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd /tmp

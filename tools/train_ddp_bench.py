@@ -31,7 +31,7 @@ def main():
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    torch.set_num_threads(max(1, (os.cpu_count() or 8) // max(world, 1)))
+    torch.set_num_threads(max(1, min(16, (os.cpu_count() or 8) // max(world, 1))))      # (a box reports all host cores; a rank owns a share)
     from mumpy_hip import distributed as D, ops
     D.init_process_group(backend, dev)
     from models.decoder.decoder import Decoder

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Experiment (round 3): does an XCD keep a strip's x panels in its L2 when it walks along N (MUMPY_WS_WALK=1, tuning build), and do
 # non-temporal output stores (libmumpy_hip_nt.so: `make -C <pkg>/csrc nt`, -DMUMPY_WS_STORE_AUX=2) help it?  FETCH_SIZE per launch + duration.
+export OMP_NUM_THREADS=${OMP_NUM_THREADS:-16}   # a box reports every host core; torch would start one thread per core
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 P=$R/multilateral-temporal-view-pyramid-transformer-for-video-inpainting-detection_amd/lib
