@@ -432,7 +432,9 @@ int mumpy_relpos_bias_expand_fwd(const float* table, const int32_t* rel_index, f
 /* GroupNorm (+ReLU) backward, NHWC (BaselineDecoder blocks, decoder.py:233-271): z, dy, dz (B,HW,C); stats_partial /
  * nsplit_stats = the partial sums mumpy_gn_stats_nhwc_fwd produced for z; `relu` is the activation that followed the
  * norm: 0 none, 1 ReLU (dy masked where GN(z) <= 0), 2 sigmoid (dy scaled by s(1-s)).
- * dgamma, dbeta (C).  Same C / G limits as mumpy_gn_stats_nhwc_fwd.  Deterministic. */
+ * dgamma, dbeta (C): written, or -- `relu | MUMPY_GN_ACCUMULATE` -- added to what the buffers hold (the caller's flat gradient
+ * buffer: no separate add launches).  Same C / G limits as mumpy_gn_stats_nhwc_fwd.  Deterministic. */
+#define MUMPY_GN_ACCUMULATE 0x100
 int64_t mumpy_gn_bwd_workspace_bytes(int B, int64_t HW, int C);
 int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int nsplit_stats, const float* gamma, const float* beta,
                       const float* dy, float* dz, float* dgamma, float* dbeta, void* workspace, int64_t workspace_bytes,

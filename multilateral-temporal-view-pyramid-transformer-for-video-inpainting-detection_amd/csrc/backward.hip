@@ -577,6 +577,9 @@ extern "C" int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int
     MUMPY_REQUIRE(C % 4 == 0 && C <= 1024 && 256 % (C / 4) == 0 && G > 0 && G <= 32 && C % G == 0 && (C / G) % 4 == 0, MUMPY_EINVAL,
                   "gn_bwd: unsupported C=%d G=%d", C, G);
     MUMPY_REQUIRE(workspace_bytes >= mumpy_gn_bwd_workspace_bytes(B, HW, C), MUMPY_EINVAL, "gn_bwd: workspace too small");
+    const int accumulate = (relu & MUMPY_GN_ACCUMULATE) ? 1 : 0;
+    relu &= ~MUMPY_GN_ACCUMULATE;
+    MUMPY_REQUIRE(relu >= 0 && relu <= 2, MUMPY_EINVAL, "gn_bwd: activation code %d", relu);
     const int ns = gn_bwd_splits(HW, C);
     float* part = static_cast<float*>(workspace);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(ns, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial, nsplit_stats, gamma,
@@ -587,13 +590,11 @@ extern "C" int mumpy_gn_bwd_nhwc(const float* z, const float* stats_partial, int
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)grid, B), dim3(256), 0, as_stream(stream), z, dy, stats_partial,
                        nsplit_stats, gamma, beta, part, dz, HW, C, G, ns, eps, relu);
     MUMPY_CHECK_LAUNCH("gn_bwd(apply)");
-    // dbeta[c] = sum over (b, split) of T1, dgamma[c] of T2: partial rows are [T1(C) | T2(C)]
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part, dbeta,
-                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
-    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dbeta)");
-    hipLaunchKernelGGL(partial_reduce_kernel, dim3((unsigned)((C + 63) / 64)), dim3(1024), 0, as_stream(stream), part + C, dgamma,
-                       (int64_t)B * ns, (int64_t)C, (int64_t)2 * C);
-    MUMPY_CHECK_LAUNCH("gn_bwd(reduce dgamma)");
+    // dbeta[c] = sum over (b, split) of T1, dgamma[c] of T2: partial rows are [T1(C) | T2(C)] -- the LayerNorm reduce's layout with
+    // the roles swapped; ONE launch for both, written or accumulated in place
+    hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), part, dbeta, dgamma,
+                       (int64_t)B * ns, C, accumulate);
+    MUMPY_CHECK_LAUNCH("gn_bwd(reduce)");
     return 0;
 }
 

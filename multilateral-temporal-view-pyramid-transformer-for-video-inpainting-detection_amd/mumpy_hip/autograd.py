@@ -364,13 +364,17 @@ class GroupNormActFn(torch.autograd.Function):
         z, partial, nsplit = ops.gn_stats(z, groups)
         ctx.save_for_backward(z, partial, gamma, beta)
         ctx.cfg = (nsplit, groups, eps, act)
+        ctx.params = (gamma, beta)
         return ops.gn_apply_resample(z, (partial, nsplit, gamma, beta, groups, eps), act=act)
 
     @staticmethod
     def backward(ctx, dy):
         z, partial, gamma, beta = ctx.saved_tensors
         nsplit, groups, eps, act = ctx.cfg
-        dz, dg, db = ops.gn_bwd(z, (partial, nsplit), gamma, beta, dy, groups, eps, act)
+        gs, bs = _grad_slot(ctx.params[0]), _grad_slot(ctx.params[1])
+        if gs is None or bs is None:
+            gs = bs = None
+        dz, dg, db = ops.gn_bwd(z, (partial, nsplit), gamma, beta, dy, groups, eps, act, dg_out=gs, db_out=bs)
         return dz, dg, db, None, None, None
 
 

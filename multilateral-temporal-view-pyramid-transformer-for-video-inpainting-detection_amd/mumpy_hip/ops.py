@@ -967,20 +967,27 @@ def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, s
     return dqkv, (None if acc else dtable)
 
 
-def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, act=ACT_RELU):
+GN_ACCUMULATE = 0x100     # mumpy_hip.h: MUMPY_GN_ACCUMULATE
+
+
+def gn_bwd(z, stats, gamma, beta, dy, groups, eps=1e-5, act=ACT_RELU, dg_out=None, db_out=None):
     """GroupNorm(+activation) backward on NHWC: z, dy logical (B,C,H,W) with NHWC memory; stats = (partial, nsplit) from
-    gn_stats(z); act = 0 / ACT_RELU / ACT_SIGMOID is the activation that followed the norm.  -> (dz like z, dgamma, dbeta)."""
+    gn_stats(z); act = 0 / ACT_RELU / ACT_SIGMOID is the activation that followed the norm.  -> (dz like z, dgamma, dbeta);
+    with dg_out AND db_out the parameter gradients are ACCUMULATED into those buffers (grad slots) and returned as None."""
     z, dy = _nhwc(z, "z"), _nhwc(dy, "dy")
     b, c, h, w = z.shape
     partial, nsplit = stats
     dz = empty_nhwc(b, c, h, w, z.device)
-    dg = torch.empty(c, device=z.device, dtype=torch.float32)
-    db = torch.empty(c, device=z.device, dtype=torch.float32)
+    acc = dg_out is not None and db_out is not None
+    dg = _chk(dg_out, "dgamma") if acc else torch.empty(c, device=z.device, dtype=torch.float32)
+    db = _chk(db_out, "dbeta") if acc else torch.empty(c, device=z.device, dtype=torch.float32)
+    if dg.numel() != c or db.numel() != c:
+        raise RuntimeError("gn_bwd: parameter gradient buffers must hold C values")
     wsb = int(_lib().mumpy_gn_bwd_workspace_bytes(b, h * w, c))
     ws = _ws(wsb, z.device)
     _call("mumpy_gn_bwd_nhwc", _p(z), _p(partial), nsplit, _p(_chk(gamma, "gamma")), _p(_chk(beta, "beta")), _p(dy), _p(dz), _p(dg),
-          _p(db), _p(ws), wsb, b, h * w, c, groups, eps, int(act), _stream(), work=20.0 * z.numel())
-    return dz, dg, db
+          _p(db), _p(ws), wsb, b, h * w, c, groups, eps, int(act) | (GN_ACCUMULATE if acc else 0), _stream(), work=20.0 * z.numel())
+    return (dz, None, None) if acc else (dz, dg, db)
 
 
 def upsample_bwd(dy, scale=2, align_corners=True):

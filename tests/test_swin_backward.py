@@ -286,6 +286,18 @@ def test_hip_groupnorm_relu_bwd(b, h, w, c, g):
     gg, bg = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
     GroupNormActFn.apply(zg, gg, bg, g, 1e-5, ops.ACT_RELU).backward(dy.cuda())
     assert rel_err(zg.grad.cpu(), zr.grad) < 5e-5 and rel_err(gg.grad.cpu(), gr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+    # parameters owned by FlatAdamW: the kernel ACCUMULATES dgamma / dbeta into the flat gradient buffer (two passes = twice)
+    from mumpy_hip.train import FlatAdamW
+    gn = torch.nn.GroupNorm(g, c).cuda()
+    with torch.no_grad():
+        gn.weight.copy_(gm.cuda()); gn.bias.copy_(bt.cuda())
+    opt = FlatAdamW(list(gn.parameters()), lr=1e-3)
+    for _ in range(2):
+        zs = z.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        GroupNormActFn.apply(zs, gn.weight, gn.bias, g, 1e-5, ops.ACT_RELU).backward(dy.cuda())
+    assert gn.weight.grad.data_ptr() == opt.grad.data_ptr()
+    assert rel_err(gn.weight.grad.cpu(), 2 * gr.grad) < 5e-5 and rel_err(gn.bias.grad.cpu(), 2 * br.grad) < 5e-5
+    assert rel_err(zs.grad.cpu(), zr.grad) < 5e-5
 
 
 @pytest.mark.gpu

@@ -9,7 +9,7 @@ pairs = {
     "stats_serial.csv": "final_serial_kernel_stats.csv", "stats_fj.csv": "final_kernel_stats.csv", "stats_s16.csv": "bf16_storage_serial_kernel_stats.csv",
     "summary_serial.md": "final_serial_summary.md", "summary_fj.md": "final_summary.md", "summary_s16.md": "bf16_storage_serial_summary.md",
     "timeline_gaps.txt": "timeline_gaps.txt", "phase_timeline.txt": "phase_timeline.txt", "gemm_shapes.txt": "gemm_shapes.txt",
-    "ln_fold_shapes.txt": "ln_fold_shapes_final.txt", "summary_train.md": "train_b2_final.md",
+    "ln_fold_shapes.txt": "ln_fold_shapes_final.txt", "summary_train.md": "train_b2_final.md", "train_aten_ops.txt": "train_aten_ops.txt",
 }
 for src, dst in pairs.items():
     s = os.path.join(G, src)

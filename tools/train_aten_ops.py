@@ -35,7 +35,7 @@ for _ in range(2):
     step()
 torch.cuda.synchronize()
 ops.PROFILE = {}
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
 ours, ops.PROFILE = ops.PROFILE, None
@@ -43,6 +43,29 @@ rows = collections.Counter()
 for ev in prof.events():
     if ev.name.startswith("aten::") and ev.kernels:
         rows[(ev.name, str(ev.input_shapes)[:110])] += len(ev.kernels)
+# device-side memcpy / memset activities (hipMemcpyAsync D2D is what a contiguous same-dtype copy_ becomes: no kernel name): every
+# device event of the step by name, and the CPU ops that own a "Memcpy" one with the innermost package frame of their stack
+dev_names = collections.Counter()
+mem_sites = collections.Counter()
+for ev in prof.events():
+    for k in ev.kernels:
+        if ev.name.startswith("aten::") or ev.cpu_parent is None or not ev.cpu_parent.name.startswith("aten::"):
+            pass
+    if ev.kernels and not any(c.kernels for c in ev.cpu_children):          # innermost CPU op owning device work
+        for k in ev.kernels:
+            dev_names[k.name.split("(")[0][:70]] += 1
+            if "emcpy" in k.name or "emset" in k.name or not k.name.strip():
+                fr = next((f for f in (ev.stack or []) if "_amd/" in f and "tools/" not in f), (ev.stack or ["?"])[0] if ev.stack else "?")
+                mem_sites[(ev.name, str(ev.input_shapes)[:70], fr.split("_amd/")[-1][:90])] += 1
+from torch.autograd import DeviceType
+n_dev = sum(1 for ev in prof.events() if ev.device_type == DeviceType.CUDA)
+print(f"device activities (kernels + memcpy / memset) in ONE step: {n_dev}")
+print("device activities of the step by name (top 25):")
+for n, c in dev_names.most_common(25):
+    print(f"{c:6d} {n}")
+print("memcpy / memset / unnamed-activity owners:")
+for (n, sh, fr), c in mem_sites.most_common(40):
+    print(f"{c:5d} {n:20s} {sh:70s} {fr}")
 tot = sum(rows.values())
 print(f"ATen-launched kernels per step: {tot};  C-ABI calls per step: {sum(len(v) for v in ours.values())}")
 by_op = collections.Counter()
