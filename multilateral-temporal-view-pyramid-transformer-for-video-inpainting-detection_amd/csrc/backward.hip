@@ -14,7 +14,7 @@ namespace {
 // LayerNorm backward (nn.LayerNorm over the last dim, eps inside the sqrt; swin:266,305).  One wave per row:
 //   xhat = (x - mean) * rstd,  g = dy * gamma,  dx = rstd * (g - mean(g) - xhat * mean(g * xhat))
 // dgamma / dbeta: each block accumulates its rows in registers (lane owns columns lane, lane+64, ...) and writes one
-// partial row per wave; ln_bwd_reduce_kernel sums the partials in order.
+// partial row per block; ln_param_reduce_kernel sums the partials in a fixed tree.
 constexpr int LN_MAXC4 = 8;             // float4 columns per lane: C <= 64 * 4 * 8 = 2048 (PatchMerging's LayerNorm(4C) at C = 512)
 
 // NC4 = float4 columns per lane (C <= 256 * NC4), RU = rows in flight per wave: narrow rows are latency-bound (three
@@ -105,13 +105,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x
             }
         }
     }
-    f32x4* pg = reinterpret_cast<f32x4*>(partial + gw * 2 * C);
-    f32x4* pb = reinterpret_cast<f32x4*>(partial + gw * 2 * C + C);
+    // one partial row [dgamma | dbeta] per BLOCK: the four waves add their registers into an LDS row in wave order (a fixed order:
+    // bitwise reproducible) -- a quarter of the rows the parameter reduce has to read (it was a row per wave)
+    extern __shared__ f32x4 lrow[];                          // [2 * n4]
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
 #pragma unroll
-    for (int i = 0; i < NC4; ++i) {
-        const int c4 = lane + 64 * i;
-        if (c4 < n4) { pg[c4] = dg[i]; pb[c4] = db[i]; }
+            for (int i = 0; i < NC4; ++i) {
+                const int c4 = lane + 64 * i;
+                if (c4 < n4) {
+                    if (w == 0) { lrow[c4] = dg[i]; lrow[n4 + c4] = db[i]; }
+                    else { lrow[c4] += dg[i]; lrow[n4 + c4] += db[i]; }
+                }
+            }
+        }
+        __syncthreads();
     }
+    f32x4* prow = reinterpret_cast<f32x4*>(partial + (int64_t)blockIdx.x * 2 * C);
+    for (int i = threadIdx.x; i < 2 * n4; i += 256) prow[i] = lrow[i];
 }
 
 // out[c] = sum_p partial[p * stride + c]: 64 columns per block, 16 lane groups each summing every 16th partial, combined
@@ -453,8 +464,8 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
     const int rpw = (int)((rows + waves - 1) / waves);
     float* partial = static_cast<float*>(workspace);
 #define MUMPY_LN_BWD(NC4_, RU_)                                                                                     \
-    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), 0, as_stream(stream), x, gamma, dy, dx_add, dx, \
-                       partial, rows, C, eps, rpw)
+    hipLaunchKernelGGL((ln_bwd_kernel<NC4_, RU_>), dim3((unsigned)(waves / 4)), dim3(256), (size_t)2 * C * sizeof(float), as_stream(stream), \
+                       x, gamma, dy, dx_add, dx, partial, rows, C, eps, rpw)
     if (C <= 256) MUMPY_LN_BWD(1, 4);
     else if (C <= 512) MUMPY_LN_BWD(2, 2);
     else if (C <= 1024) MUMPY_LN_BWD(4, 1);
@@ -462,7 +473,7 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
 #undef MUMPY_LN_BWD
     MUMPY_CHECK_LAUNCH("layernorm_bwd");
     hipLaunchKernelGGL(ln_param_reduce_kernel, dim3((unsigned)((2 * C + 63) / 64)), dim3(1024), 0, as_stream(stream), partial, dgamma,
-                       dbeta, waves, C, accumulate);
+                       dbeta, waves / 4, C, accumulate);
     MUMPY_CHECK_LAUNCH("layernorm_bwd(reduce)");
     return 0;
 }

@@ -11,69 +11,81 @@ using namespace mumpy;
 namespace {
 
 // u[n][p][c] = b[c] + sum_{dy,dx in [-2,2]} x[n][p + (dy,dx)][c] * w[c][(dy+2)*5 + (dx+2)]   (zero padding inside the 7x7 window)
-__global__ __launch_bounds__(256) void dwconv5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// Round 3: one THREAD per (window, channel) with the channel's 49 pixels and 25 taps in registers and the 7x7x5x5 loop nest fully
+// unrolled (bounds are compile-time constants: ~750 FMAs, no LDS, no index arithmetic); loads and stores are coalesced over the
+// channel.  (The first version staged the window in LDS and spent its time on address arithmetic and 25 LDS reads per output.)
+// grid (N, ceil(C / 128)), 128 threads.
+__global__ __launch_bounds__(128) void dwconv5_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ b, float* __restrict__ u, int C) {
-    extern __shared__ float sm[];                     // the window: 49 * C floats
-    const int n = blockIdx.x;
-    const float* xn = x + (int64_t)n * WT * C;
-    for (int i = threadIdx.x; i < WT * C; i += 256) sm[i] = xn[i];
-    __syncthreads();
-    for (int i = threadIdx.x; i < WT * C; i += 256) {
-        const int c = i % C, p = i / C, y = p / WS, xx = p - y * WS;
-        float acc = b[c];
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c >= C) return;
+    const float* xn = x + (int64_t)blockIdx.x * WT * C + c;
+    float xv[WT], wv[25];
 #pragma unroll
-        for (int dy = -2; dy <= 2; ++dy)
+    for (int p = 0; p < WT; ++p) xv[p] = xn[(int64_t)p * C];
 #pragma unroll
-            for (int dx = -2; dx <= 2; ++dx) {
-                const int yy = y + dy, xq = xx + dx;
-                if ((unsigned)yy < (unsigned)WS && (unsigned)xq < (unsigned)WS)
-                    acc = fmaf(sm[(yy * WS + xq) * C + c], w[c * 25 + (dy + 2) * 5 + (dx + 2)], acc);
-            }
-        u[(int64_t)n * WT * C + i] = acc;
-    }
+    for (int t = 0; t < 25; ++t) wv[t] = w[c * 25 + t];
+    const float bias = b[c];
+    float* un = u + (int64_t)blockIdx.x * WT * C + c;
+#pragma unroll
+    for (int y = 0; y < WS; ++y)
+#pragma unroll
+        for (int xx = 0; xx < WS; ++xx) {
+            float acc = bias;
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+                for (int dx = -2; dx <= 2; ++dx) {
+                    const int yy = y + dy, xq = xx + dx;
+                    if (yy >= 0 && yy < WS && xq >= 0 && xq < WS) acc = fmaf(xv[yy * WS + xq], wv[(dy + 2) * 5 + (dx + 2)], acc);
+                }
+            un[(int64_t)(y * WS + xx) * C] = acc;
+        }
 }
 
-// dx[n][p][c] = sum_taps du[n][p - tap][c] w[c][tap];  part[n][26][C] = {dw[tap][c] (25 rows), db[c]} of this window
-__global__ __launch_bounds__(256) void dwconv5_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// dx[n][p][c] = sum_taps du[n][p - tap][c] w[c][tap];  part[n][26][C] = {dw[tap][c] (25 rows), db[c]} of this window.
+// Same thread-per-channel, all-in-registers form (summation orders as in the first version: taps in order, pixels in order).
+__global__ __launch_bounds__(128) void dwconv5_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           const float* __restrict__ du, float* __restrict__ dx,
                                                           float* __restrict__ part, int C) {
-    extern __shared__ float sm[];                     // x window then du window: 2 * 49 * C floats
-    float* sx = sm;
-    float* sd = sm + WT * C;
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < WT * C; i += 256) {
-        sx[i] = x[(int64_t)n * WT * C + i];
-        sd[i] = du[(int64_t)n * WT * C + i];
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < WT * C; i += 256) {
-        const int c = i % C, p = i / C, y = p / WS, xx = p - y * WS;
-        float acc = 0.f;
+    const int c = blockIdx.y * 128 + threadIdx.x;
+    if (c >= C) return;
+    const int64_t base = (int64_t)blockIdx.x * WT * C + c;
+    float xv[WT], dv[WT], wv[25];
 #pragma unroll
-        for (int dy = -2; dy <= 2; ++dy)
+    for (int p = 0; p < WT; ++p) { xv[p] = x[base + (int64_t)p * C]; dv[p] = du[base + (int64_t)p * C]; }
 #pragma unroll
-            for (int dx_ = -2; dx_ <= 2; ++dx_) {
-                const int yy = y - dy, xq = xx - dx_;             // output pixel that read this input through tap (dy,dx)
-                if ((unsigned)yy < (unsigned)WS && (unsigned)xq < (unsigned)WS)
-                    acc = fmaf(sd[(yy * WS + xq) * C + c], w[c * 25 + (dy + 2) * 5 + (dx_ + 2)], acc);
-            }
-        dx[(int64_t)n * WT * C + i] = acc;
-    }
-    // weight / bias gradient partials of this window: one thread per (tap or bias, channel), pixels in order
-    for (int i = threadIdx.x; i < 26 * C; i += 256) {
-        const int c = i % C, tap = i / C;
-        float acc = 0.f;
-        if (tap == 25) {
-            for (int p = 0; p < WT; ++p) acc += sd[p * C + c];
-        } else {
-            const int dy = tap / 5 - 2, dx_ = tap % 5 - 2;
-            for (int p = 0; p < WT; ++p) {
-                const int y = p / WS, xx = p - y * WS, yy = y + dy, xq = xx + dx_;
-                if ((unsigned)yy < (unsigned)WS && (unsigned)xq < (unsigned)WS) acc = fmaf(sd[p * C + c], sx[(yy * WS + xq) * C + c], acc);
-            }
+    for (int t = 0; t < 25; ++t) wv[t] = w[c * 25 + t];
+#pragma unroll
+    for (int y = 0; y < WS; ++y)
+#pragma unroll
+        for (int xx = 0; xx < WS; ++xx) {
+            float acc = 0.f;
+#pragma unroll
+            for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+                for (int dx_ = -2; dx_ <= 2; ++dx_) {
+                    const int yy = y - dy, xq = xx - dx_;             // output pixel that read this input through tap (dy,dx)
+                    if (yy >= 0 && yy < WS && xq >= 0 && xq < WS) acc = fmaf(dv[yy * WS + xq], wv[(dy + 2) * 5 + (dx_ + 2)], acc);
+                }
+            dx[base + (int64_t)(y * WS + xx) * C] = acc;
         }
-        part[((int64_t)n * 26 + tap) * C + c] = acc;
+    float* pn = part + (int64_t)blockIdx.x * 26 * C + c;
+#pragma unroll
+    for (int tap = 0; tap < 25; ++tap) {
+        const int dy = tap / 5 - 2, dx_ = tap % 5 - 2;
+        float acc = 0.f;
+#pragma unroll
+        for (int p = 0; p < WT; ++p) {
+            const int y = p / WS, xx = p - y * WS, yy = y + dy, xq = xx + dx_;
+            if (yy >= 0 && yy < WS && xq >= 0 && xq < WS) acc = fmaf(dv[p], xv[yy * WS + xq], acc);
+        }
+        pn[(int64_t)tap * C] = acc;
     }
+    float sb = 0.f;
+#pragma unroll
+    for (int p = 0; p < WT; ++p) sb += dv[p];
+    pn[(int64_t)25 * C] = sb;
 }
 
 // fixed-order sum over windows: out[i] = sum_n part[n * width + i]   (16 lane groups, as partial_reduce in backward.hip)
@@ -111,52 +123,81 @@ __device__ __forceinline__ Corner corner_of(float py, float px) {
     return k;
 }
 
-// grid (B2, 3): one block per (kv window, channel group) -- a group's x2 / dsampled slices (2 * 49 * Cg floats) fit LDS
+// grid (B2, 3): one block per (kv window, channel group) -- a group's x2 / dsampled slices (2 * 49 * Cg floats) fit LDS.
+// Round 3: the corner of every point is computed ONCE and each pixel gets the list of (point, weight) pairs that touch it, in point
+// order (the first version recomputed all 49 corners in every (pixel, channel) thread); the position gradient is a wave per point
+// with the channels across lanes and a fixed-tree wave sum (it was one THREAD per point walking Cg channels).  178 -> see DESIGN 7c.
+constexpr int SB_LIST = WT;                       // worst case: every point lands on one pixel
 __global__ __launch_bounds__(256) void deform_sample_bwd_kernel(const float* __restrict__ x2, const float* __restrict__ pos,
                                                                 const float* __restrict__ ds, float* __restrict__ dx2,
                                                                 float* __restrict__ dpos_part, int C, int nq) {
-    extern __shared__ float sm[];                     // x2 slice (49*Cg) | dsampled slice (49*Cg) | pos of the group (49*2)
+    extern __shared__ float sm[];     // x2 slice (49*Cg) | dsampled slice (49*Cg) | pos (49*2) | corners (49*4) | counts (49) | lists
     const int b2 = blockIdx.x, g = blockIdx.y, Cg = C / 3;
     float* sx = sm;
     float* sd = sm + WT * Cg;
     float* sp = sm + 2 * WT * Cg;
+    float* sc = sp + WT * 2;                                      // per point: y0, x0 (as floats: |values| <= 8), ly, lx
+    int* cnt = reinterpret_cast<int*>(sc + WT * 4);
+    int* lp = cnt + WT;                                           // [pixel][SB_LIST] point index
+    float* lw = reinterpret_cast<float*>(lp + WT * SB_LIST);      // [pixel][SB_LIST] weight
     for (int i = threadIdx.x; i < WT * Cg; i += 256) {
         const int c = i % Cg, p = i / Cg;
         sx[i] = x2[((int64_t)b2 * WT + p) * C + g * Cg + c];
         sd[i] = ds[((int64_t)b2 * WT + p) * C + g * Cg + c];
     }
     const float* pq = pos + ((int64_t)(b2 % nq) * 3 + g) * WT * 2;
-    for (int i = threadIdx.x; i < WT * 2; i += 256) sp[i] = pq[i];
+    if (threadIdx.x < WT) {
+        const int p = threadIdx.x;
+        const float py = pq[p * 2], px = pq[p * 2 + 1];
+        sp[p * 2] = py; sp[p * 2 + 1] = px;
+        const Corner k = corner_of(py, px);
+        sc[p * 4] = (float)k.y0; sc[p * 4 + 1] = (float)k.x0; sc[p * 4 + 2] = k.ly; sc[p * 4 + 3] = k.lx;
+    }
     __syncthreads();
-    // dx2: thread per (pixel, channel); the 49 points in order
-    for (int i = threadIdx.x; i < WT * Cg; i += 256) {
-        const int c = i % Cg, pix = i / Cg, y = pix / WS, x = pix - y * WS;
-        float acc = 0.f;
+    if (threadIdx.x < WT) {                                       // pixel -> its (point, weight) pairs, points in order
+        const int pix = threadIdx.x, y = pix / WS, x = pix - y * WS;
+        int n = 0;
         for (int p = 0; p < WT; ++p) {
-            const Corner k = corner_of(sp[p * 2], sp[p * 2 + 1]);
-            const float wy = (k.y0 == y ? 1.0f - k.ly : 0.f) + (k.y0 + 1 == y ? k.ly : 0.f);
-            const float wx = (k.x0 == x ? 1.0f - k.lx : 0.f) + (k.x0 + 1 == x ? k.lx : 0.f);
+            const int y0 = (int)sc[p * 4], x0 = (int)sc[p * 4 + 1];
+            const float ly = sc[p * 4 + 2], lx = sc[p * 4 + 3];
+            const float wy = (y0 == y ? 1.0f - ly : 0.f) + (y0 + 1 == y ? ly : 0.f);
+            const float wx = (x0 == x ? 1.0f - lx : 0.f) + (x0 + 1 == x ? lx : 0.f);
             const float wgt = wy * wx;
-            if (wgt != 0.f) acc = fmaf(wgt, sd[p * Cg + c], acc);
+            if (wgt != 0.f) { lp[pix * SB_LIST + n] = p; lw[pix * SB_LIST + n] = wgt; ++n; }
         }
+        cnt[pix] = n;
+    }
+    __syncthreads();
+    // dx2: thread per (pixel, channel); the pixel's points in order (the same products and order as a walk over all 49)
+    for (int i = threadIdx.x; i < WT * Cg; i += 256) {
+        const int c = i % Cg, pix = i / Cg, n = cnt[pix];
+        float acc = 0.f;
+        for (int j = 0; j < n; ++j) acc = fmaf(lw[pix * SB_LIST + j], sd[lp[pix * SB_LIST + j] * Cg + c], acc);
         dx2[((int64_t)b2 * WT + pix) * C + g * Cg + c] = acc;
     }
-    // dpos: one thread per point; channels of the group in order
-    for (int p = threadIdx.x; p < WT; p += 256) {
-        const Corner k = corner_of(sp[p * 2], sp[p * 2 + 1]);
-        auto px = [&](int yy, int xx, int c) -> float {
-            return ((unsigned)yy < (unsigned)WS && (unsigned)xx < (unsigned)WS) ? sx[(yy * WS + xx) * Cg + c] : 0.f;
-        };
+    // dpos: a wave per point, channels across the lanes (lane, lane + 64, ...), fixed-tree wave sums
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int p = wave; p < WT; p += 4) {
+        const int y0 = (int)sc[p * 4], x0 = (int)sc[p * 4 + 1];
+        const float ly = sc[p * 4 + 2], lx = sc[p * 4 + 3];
+        const bool in_y0 = (unsigned)y0 < (unsigned)WS, in_y1 = (unsigned)(y0 + 1) < (unsigned)WS;
+        const bool in_x0 = (unsigned)x0 < (unsigned)WS, in_x1 = (unsigned)(x0 + 1) < (unsigned)WS;
+        const int o00 = (y0 * WS + x0) * Cg, o01 = o00 + Cg, o10 = o00 + WS * Cg, o11 = o10 + Cg;
         float gy = 0.f, gx = 0.f;
-        for (int c = 0; c < Cg; ++c) {
-            const float v00 = px(k.y0, k.x0, c), v01 = px(k.y0, k.x0 + 1, c), v10 = px(k.y0 + 1, k.x0, c), v11 = px(k.y0 + 1, k.x0 + 1, c);
+        for (int c = lane; c < Cg; c += 64) {
+            const float v00 = (in_y0 && in_x0) ? sx[o00 + c] : 0.f, v01 = (in_y0 && in_x1) ? sx[o01 + c] : 0.f;
+            const float v10 = (in_y1 && in_x0) ? sx[o10 + c] : 0.f, v11 = (in_y1 && in_x1) ? sx[o11 + c] : 0.f;
             const float d = sd[p * Cg + c];
-            gy = fmaf(d, (v10 - v00) * (1.0f - k.lx) + (v11 - v01) * k.lx, gy);
-            gx = fmaf(d, (v01 - v00) * (1.0f - k.ly) + (v11 - v10) * k.ly, gx);
+            gy = fmaf(d, (v10 - v00) * (1.0f - lx) + (v11 - v01) * lx, gy);
+            gx = fmaf(d, (v01 - v00) * (1.0f - ly) + (v11 - v10) * ly, gx);
         }
-        float* o = dpos_part + (((int64_t)b2 * 3 + g) * WT + p) * 2;
-        o[0] = 3.0f * gy;                                    // d f / d pos = 3 (half the 6-pixel span)
-        o[1] = 3.0f * gx;
+        gy = wave_sum(gy, 64);
+        gx = wave_sum(gx, 64);
+        if (lane == 0) {
+            float* o = dpos_part + (((int64_t)b2 * 3 + g) * WT + p) * 2;
+            o[0] = 3.0f * gy;                                    // d f / d pos = 3 (half the 6-pixel span)
+            o[1] = 3.0f * gx;
+        }
     }
 }
 
@@ -166,13 +207,7 @@ extern "C" int mumpy_dwconv5_window_fwd(const float* x, const float* w, const fl
     if (N == 0) return 0;
     MUMPY_REQUIRE(x && w && b && u, MUMPY_ENULL, "dwconv5: null pointer");
     MUMPY_REQUIRE(N > 0 && N < (1ll << 31) && C > 0 && C <= 384, MUMPY_EINVAL, "dwconv5: bad shape (C=%d)", C);
-    const size_t lds = WT * C * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv5_fwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        MUMPY_REQUIRE(e == hipSuccess, (int)e, "dwconv5: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(dwconv5_fwd_kernel, dim3((unsigned)N), dim3(256), lds, as_stream(stream), x, w, b, u, C);
+    hipLaunchKernelGGL(dwconv5_fwd_kernel, dim3((unsigned)N, (unsigned)((C + 127) / 128)), dim3(128), 0, as_stream(stream), x, w, b, u, C);
     MUMPY_CHECK_LAUNCH("dwconv5_fwd");
     return 0;
 }
@@ -187,13 +222,7 @@ extern "C" int mumpy_dwconv5_window_bwd(const float* x, const float* w, const fl
     MUMPY_REQUIRE(N > 0 && N < (1ll << 31) && C > 0 && C <= 384, MUMPY_EINVAL, "dwconv5_bwd: bad shape (C=%d)", C);
     MUMPY_REQUIRE(workspace_bytes >= mumpy_dwconv5_window_bwd_workspace_bytes(N, C), MUMPY_EINVAL, "dwconv5_bwd: workspace too small");
     float* part = static_cast<float*>(workspace);
-    const size_t lds = 2 * WT * C * sizeof(float);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(dwconv5_bwd_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        MUMPY_REQUIRE(e == hipSuccess, (int)e, "dwconv5_bwd: cannot raise the dynamic LDS limit: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(dwconv5_bwd_kernel, dim3((unsigned)N), dim3(256), lds, as_stream(stream), x, w, du, dx, part, C);
+    hipLaunchKernelGGL(dwconv5_bwd_kernel, dim3((unsigned)N, (unsigned)((C + 127) / 128)), dim3(128), 0, as_stream(stream), x, w, du, dx, part, C);
     MUMPY_CHECK_LAUNCH("dwconv5_bwd");
     // part rows are [tap 0..24][C] then [bias][C]; dw is (C, 25) like the module's (C,1,5,5) weight: reduce to a (26, C) image,
     // the caller transposes the first 25 rows (mumpy_hip/autograd.py)
@@ -210,7 +239,7 @@ extern "C" int mumpy_deform_sample_bwd(const float* x2, const float* pos, const 
                                        int64_t B2, int C, int nq, void* stream) {
     MUMPY_REQUIRE(x2 && pos && dsampled && dx2 && dpos_part, MUMPY_ENULL, "deform_sample_bwd: null pointer");
     MUMPY_REQUIRE(B2 > 0 && B2 < (1ll << 31) && C > 0 && C % 3 == 0 && C <= 768 && nq > 0, MUMPY_EINVAL, "deform_sample_bwd: bad shape");
-    const size_t lds = (2 * WT * (C / 3) + WT * 2) * sizeof(float);
+    const size_t lds = (2 * WT * (C / 3) + WT * 2 + WT * 4 + WT + 2 * WT * WT) * sizeof(float);      // slices, pos, corners, counts, lists
     MUMPY_REQUIRE(lds <= 160 * 1024, MUMPY_ERANGE, "deform_sample_bwd: window does not fit LDS");
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(deform_sample_bwd_kernel),

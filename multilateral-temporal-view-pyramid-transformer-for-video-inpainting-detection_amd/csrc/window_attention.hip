@@ -917,6 +917,23 @@ __global__ __launch_bounds__(64) void win_attn_dtable_kernel(const float* __rest
     if (lane == 0) dtable[(int64_t)t * nH + head] = accum ? dtable[(int64_t)t * nH + head] + s : s;
 }
 
+// the same through the inverse of relative_position_index (built once by the caller): csr = [ptr (ntab + 1) | pairs (49*49)], the pairs
+// p = 49 i + j of table entry t are pairs[ptr[t] .. ptr[t+1]) in increasing p.  A wave per (t, head) reads ITS <= 49 values (the scan
+// above walks all 2401 index entries in every one of the 169 x nH waves: 20 us per Swin block of the training step, 60 blocks).
+__global__ __launch_bounds__(256) void win_attn_dtable_csr_kernel(const float* __restrict__ full, const int32_t* __restrict__ csr,
+                                                                 float* __restrict__ dtable, int nH, int ntab, int accum) {
+    const int lane = threadIdx.x & 63, t = blockIdx.x * 4 + (threadIdx.x >> 6), head = blockIdx.y;
+    if (t >= ntab) return;
+    const int p0 = csr[t], p1 = csr[t + 1];
+    float s = 0.f;
+    for (int e = p0 + lane; e < p1; e += 64) {
+        const int p = csr[ntab + 1 + e], i = p / WT, j = p - i * WT;
+        s += full[(int64_t)head * 4096 + i * 64 + j];
+    }
+    s = wave_sum(s, 64);
+    if (lane == 0) dtable[(int64_t)t * nH + head] = accum ? dtable[(int64_t)t * nH + head] + s : s;
+}
+
 // relative_position_bias_table (169, nH) + relative_position_index (49*49, int32) -> padded bias (nH, 64, 64) [head][query][key]:
 // rows >= 49 zero, key columns >= 49 = -1e30 (the 49 -> 64 padding mask of the attention kernels; swin:148-151)
 __global__ __launch_bounds__(256) void relpos_bias_expand_kernel(const float* __restrict__ table, const int32_t* __restrict__ rel_index,
@@ -1026,8 +1043,8 @@ extern "C" int64_t mumpy_window_attention_bwd_workspace_bytes(int B, int Hs, int
     return (stats + part + (int64_t)nH * 4096) * (int64_t)sizeof(float);
 }
 
-extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
-                                          const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv,
+static int window_attention_bwd_impl(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
+                                          const int32_t* mask_id, int n_mask, const int32_t* rel_index, const int32_t* rel_csr, float* dqkv,
                                           float* dtable, void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C,
                                           int shift, float scale, int accumulate, void* stream) {
     MUMPY_REQUIRE(qkv && dout && bias && rel_index && dqkv && dtable && workspace, MUMPY_ENULL, "window_attention_bwd: null pointer");
@@ -1060,10 +1077,31 @@ extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, c
                        (int)grid);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dbias reduce)");
     const int ntab = (2 * WS - 1) * (2 * WS - 1);
-    hipLaunchKernelGGL(win_attn_dtable_kernel, dim3(ntab, a.nH), dim3(64), 0, as_stream(stream), full, rel_index, dtable, a.nH,
-                       ntab, accumulate);
+    if (rel_csr)
+        hipLaunchKernelGGL(win_attn_dtable_csr_kernel, dim3((ntab + 3) / 4, a.nH), dim3(256), 0, as_stream(stream), full, rel_csr, dtable,
+                           a.nH, ntab, accumulate);
+    else
+        hipLaunchKernelGGL(win_attn_dtable_kernel, dim3(ntab, a.nH), dim3(64), 0, as_stream(stream), full, rel_index, dtable, a.nH,
+                           ntab, accumulate);
     MUMPY_CHECK_LAUNCH("window_attention_bwd(dtable)");
     return 0;
+}
+
+extern "C" int mumpy_window_attention_bwd(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
+                                          const int32_t* mask_id, int n_mask, const int32_t* rel_index, float* dqkv,
+                                          float* dtable, void* workspace, int64_t workspace_bytes, int B, int Hs, int W, int C,
+                                          int shift, float scale, int accumulate, void* stream) {
+    return window_attention_bwd_impl(qkv, dout, bias, mask_tab, mask_id, n_mask, rel_index, nullptr, dqkv, dtable, workspace,
+                                     workspace_bytes, B, Hs, W, C, shift, scale, accumulate, stream);
+}
+
+extern "C" int mumpy_window_attention_bwd_csr(const float* qkv, const float* dout, const float* bias, const float* mask_tab,
+                                              const int32_t* mask_id, int n_mask, const int32_t* rel_index, const int32_t* rel_csr,
+                                              float* dqkv, float* dtable, void* workspace, int64_t workspace_bytes, int B, int Hs, int W,
+                                              int C, int shift, float scale, int accumulate, void* stream) {
+    MUMPY_REQUIRE(rel_csr, MUMPY_ENULL, "window_attention_bwd_csr: null inverse index");
+    return window_attention_bwd_impl(qkv, dout, bias, mask_tab, mask_id, n_mask, rel_index, rel_csr, dqkv, dtable, workspace,
+                                     workspace_bytes, B, Hs, W, C, shift, scale, accumulate, stream);
 }
 
 extern "C" int mumpy_relpos_bias_expand_fwd(const float* table, const int32_t* rel_index, float* out, int nH, void* stream) {

@@ -210,17 +210,17 @@ class WindowAttentionFn(torch.autograd.Function):
         b, hs, w, c, shift, scale = dims
         idx32 = ops.rel_index32(rel_index)
         bias_pad = ops.expand_relpos_bias(table.detach(), idx32)
-        ctx.save_for_backward(qkv, bias_pad, idx32)
+        ctx.save_for_backward(qkv, bias_pad, idx32, ops.rel_index_csr(rel_index))      # (both index images are cached on the buffer)
         ctx.dims, ctx.mask = dims, (mask_tab, mask_id)
         ctx.table = table
         return ops.window_attention(qkv, bias_pad, b, hs, w, c, shift, scale, mask_tab, mask_id)
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, bias_pad, idx32 = ctx.saved_tensors
+        qkv, bias_pad, idx32, csr = ctx.saved_tensors
         b, hs, w, c, shift, scale = ctx.dims
         dqkv, dtable = ops.window_attention_bwd(qkv, dout.contiguous(), bias_pad, idx32, b, hs, w, c, shift, scale, *ctx.mask,
-                                                dtable_out=_grad_slot(ctx.table) if ctx.needs_input_grad[1] else None)
+                                                dtable_out=_grad_slot(ctx.table) if ctx.needs_input_grad[1] else None, rel_csr=csr)
         return dqkv, dtable, None, None, None, None
 
 

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mumpy_linear_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_f, c_l, c_f],
     "mumpy_window_attention_bwd_workspace_bytes": [c_i, c_i, c_i, c_i],
     "mumpy_window_attention_bwd": [c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f],
+    "mumpy_window_attention_bwd_csr": [c_f, c_f, c_f, c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_i, c_fl, c_i, c_f],
     "mumpy_relpos_bias_expand_fwd": [c_f, c_f, c_f, c_i, c_f],
     "mumpy_gn_bwd_workspace_bytes": [c_i, c_l, c_i],
     "mumpy_gn_bwd_nhwc": [c_f, c_f, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_l, c_i, c_i, c_fl, c_i, c_f],

@@ -942,9 +942,28 @@ def col_sum(x2d):
     return out
 
 
-def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None, dtable_out=None):
+def rel_index_csr(index: torch.Tensor) -> torch.Tensor:
+    """Inverse of a `relative_position_index` buffer for the table-gradient kernel: int32 [ptr (170) | pairs (2401)], the pairs
+    p = 49 i + j of one table entry contiguous and in increasing order.  Built once (host side, one synchronisation) and kept ON the
+    buffer object like rel_index32's image: call it from the forward (eager warm-up), never for the first time under graph capture."""
+    t = getattr(index, "_mumpy_csr", None)
+    if t is None or t.device != index.device or getattr(index, "_mumpy_csr_version", -1) != index._version:
+        idx = index.reshape(-1).to("cpu", torch.int64)
+        if idx.numel() != 49 * 49 or int(idx.min()) < 0 or int(idx.max()) >= 169:
+            raise RuntimeError("rel_index_csr: expected a (49,49) relative_position_index with values in [0, 169)")
+        order = torch.sort(idx, stable=True).indices
+        ptr = torch.zeros(170, dtype=torch.int64)
+        ptr[1:] = torch.cumsum(torch.bincount(idx, minlength=169), 0)
+        t = torch.cat([ptr, order]).to(torch.int32).to(index.device)
+        index._mumpy_csr, index._mumpy_csr_version = t, index._version
+    return t
+
+
+def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, scale, mask_tab=None, mask_id=None, dtable_out=None,
+                         rel_csr=None):
     """-> (dqkv (B, hs*w, 3C), dtable (169, C/32)): gradients of the W-MSA core wrt qkv and the relative position bias table.
-    dtable_out: a gradient buffer to ACCUMULATE into (the returned dtable is then None)."""
+    dtable_out: a gradient buffer to ACCUMULATE into (the returned dtable is then None).  rel_csr = rel_index_csr(index): the table
+    gradient reads its pairs through the inverse index instead of scanning the index."""
     qkv, dout = _chk(qkv, "qkv"), _chk(dout, "dout")
     if qkv.numel() != b * hs * w * 3 * c or dout.numel() != b * hs * w * c:
         raise RuntimeError("window_attention_bwd: shape mismatch")
@@ -961,8 +980,11 @@ def window_attention_bwd(qkv, dout, bias_pad, rel_index32, b, hs, w, c, shift, s
         wsb = _WS_BYTES[key] = int(_lib().mumpy_window_attention_bwd_workspace_bytes(b, hs, w, c))
     ws = _ws(wsb, qkv.device)
     n_mask = 0 if mask_id is None else mask_id.numel()
-    _call("mumpy_window_attention_bwd", _p(qkv), _p(dout), _p(_chk(bias_pad, "bias")), _p(mask_tab), _p(mask_id), n_mask,
-          _p(rel_index32.contiguous()), _p(dqkv), _p(dtable), _p(ws), wsb, b, hs, w, c, shift, scale, int(acc), _stream(),
+    if rel_csr is not None and (rel_csr.dtype != torch.int32 or rel_csr.numel() != 170 + 49 * 49 or rel_csr.device != qkv.device):
+        raise RuntimeError("window_attention_bwd: rel_csr must come from ops.rel_index_csr on this device")
+    csr_args = () if rel_csr is None else (_p(rel_csr),)
+    _call("mumpy_window_attention_bwd" + ("" if rel_csr is None else "_csr"), _p(qkv), _p(dout), _p(_chk(bias_pad, "bias")), _p(mask_tab),
+          _p(mask_id), n_mask, _p(rel_index32.contiguous()), *csr_args, _p(dqkv), _p(dtable), _p(ws), wsb, b, hs, w, c, shift, scale, int(acc), _stream(),
           work=5 * 153664.0 * b * (hs // 7) * (w // 7) * (c // 32))
     return dqkv, (None if acc else dtable)
 

@@ -229,6 +229,15 @@ def test_hip_window_attention_bwd_vs_oracle(b, hs, w, c, shift):
     y.backward(dout.cuda())
     assert rel_err(qg.grad.cpu(), qr.grad) < 2e-5
     assert rel_err(tg.grad.cpu(), tr.grad) < 2e-5
+    # the table gradient through the inverse index (what WindowAttentionFn uses) against the index-scanning kernel of the plain entry
+    idx_gpu = idx.cuda()
+    bias = ops.expand_relpos_bias(tg.detach(), ops.rel_index32(idx_gpu))
+    args = (qg.detach(), dout.cuda(), bias, ops.rel_index32(idx_gpu), b, hs, w, c, shift, 32 ** -0.5, tab, ids)
+    d_scan, t_scan = ops.window_attention_bwd(*args)
+    d_csr, t_csr = ops.window_attention_bwd(*args, rel_csr=ops.rel_index_csr(idx_gpu))
+    assert torch.equal(d_scan, d_csr) and rel_err(t_csr.cpu(), t_scan.cpu()) < 1e-6
+    csr = ops.rel_index_csr(idx_gpu).cpu()
+    assert int(csr[169]) == 49 * 49 and sorted(csr[170:].tolist()) == list(range(49 * 49))
 
 
 @pytest.mark.gpu
