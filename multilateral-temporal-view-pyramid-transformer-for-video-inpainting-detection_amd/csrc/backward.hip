@@ -438,16 +438,20 @@ __global__ __launch_bounds__(256) void upsample_bwd_kernel(const float* __restri
 
 }  // namespace
 
-static int64_t ln_bwd_waves(int64_t rows) {            // waves (= partial rows): enough to fill the chip, >= 8 rows each
-    int64_t w = (rows + 7) / 8;
-    if (w > 2048) w = 2048;
+// waves of the launch (four per block, one partial row per block).  A wave walks its rows RU at a time and every step is three
+// dependent wave reductions (~2 us): with 8 rows per wave the B = 2 shapes of config 5 (a few thousand rows) ran 60 blocks for
+// 19 us; two steps per wave fill the chip and finish in a third of that.  Capped where the rows alone fill the chip many times over.
+static int64_t ln_bwd_waves(int64_t rows, int C) {
+    const int ru = C <= 256 ? 4 : C <= 512 ? 2 : 1;
+    int64_t w = (rows + 2 * ru - 1) / (2 * ru);
+    if (w > 4096) w = 4096;
     if (w < 4) w = 4;
     return (w + 3) / 4 * 4;
 }
 
 extern "C" int64_t mumpy_layernorm_bwd_workspace_bytes(int64_t rows, int C) {
     if (rows <= 0 || C <= 0) return 0;
-    return (ln_bwd_waves(rows) + 1) * 2 * C * (int64_t)sizeof(float);      // partial rows + one reduced [dgamma | dbeta] row
+    return (ln_bwd_waves(rows, C) / 4 + 1) * 2 * C * (int64_t)sizeof(float);      // one partial [dgamma | dbeta] row per block (+ one spare)
 }
 
 extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const float* dy, const float* dx_add, float* dx,
@@ -460,7 +464,7 @@ extern "C" int mumpy_layernorm_bwd(const float* x, const float* gamma, const flo
     MUMPY_REQUIRE(accumulate == 0 || accumulate == 1, MUMPY_EINVAL, "layernorm_bwd: accumulate must be 0 or 1");
     MUMPY_REQUIRE(rows > 0 && C > 0 && C % 4 == 0 && C <= 64 * 4 * LN_MAXC4, MUMPY_EINVAL, "layernorm_bwd: unsupported C=%d", C);
     MUMPY_REQUIRE(workspace_bytes >= mumpy_layernorm_bwd_workspace_bytes(rows, C), MUMPY_EINVAL, "layernorm_bwd: workspace too small");
-    const int64_t waves = ln_bwd_waves(rows);
+    const int64_t waves = ln_bwd_waves(rows, C);
     const int rpw = (int)((rows + waves - 1) / waves);
     float* partial = static_cast<float*>(workspace);
 #define MUMPY_LN_BWD(NC4_, RU_)                                                                                     \
