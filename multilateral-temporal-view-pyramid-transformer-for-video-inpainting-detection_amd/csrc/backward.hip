@@ -282,20 +282,6 @@ __global__ __launch_bounds__(256) void conv_weight_dgrad_kernel(const float* __r
 //   S1_g = sum_{c in g} gamma_c T1[c],  S2_g = sum_{c in g} gamma_c T2[c],  T1[c] = sum_pixels g,  T2[c] = sum_pixels g xhat
 // pass 1 (grid (nsplit, B)): per-channel T1, T2 of its pixel range -> part[b][split][{T1,T2}][C]; pass 2: dz.
 // mean / rstd come from the forward's gn_stats partial sums (same layout, same fixed-order sum as the forward apply).
-__device__ __forceinline__ void gn_group_stats(const float* __restrict__ stats, int nsplit_s, int G, int b, int g, double n,
-                                               float eps, float& mean, float& rstd) {
-    double s = 0.0, q = 0.0;                                  // as in gn_apply_resample_kernel (decoder.hip): double, same order
-    for (int sp = 0; sp < nsplit_s; ++sp) {
-        const float* o = stats + (((int64_t)b * nsplit_s + sp) * G + g) * 2;
-        s += (double)o[0]; q += (double)o[1];
-    }
-    const double m = s / n;
-    double var = q / n - m * m;
-    if (var < 0.0) var = 0.0;
-    mean = (float)m;
-    rstd = (float)(1.0 / sqrt(var + (double)eps));
-}
-
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __restrict__ z, const float* __restrict__ dy,
                                                              const float* __restrict__ stats, int nsplit_s,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -306,8 +292,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(const float* __rest
     const int split = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
     const int lpp = C >> 2, ppi = 256 / lpp, c4 = tid % lpp, pl = tid / lpp;
     const int cg = C / G;
-    if (tid < G) gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
-    __syncthreads();
+    __shared__ double gred[256][2];
+    gn_block_stats(stats, nsplit_s, G, b, (double)HW * (double)cg, eps, gm, gr, gred);
     const int64_t per = (HW + nsplit - 1) / nsplit;
     const int64_t p0 = split * per, p1 = (p0 + per < HW) ? p0 + per : HW;
     f32x4 t1 = {0, 0, 0, 0}, t2 = {0, 0, 0, 0};
@@ -352,19 +338,25 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ part, float* __restrict__ dz, int64_t HW, int C,
                                                            int G, int nsplit, float eps, int relu) {
     __shared__ float gm[32], gr[32], s1[32], s2[32];
+    __shared__ float c1[1024], c2[1024];                 // per channel: gamma * (sum over the splits of T1, T2)
     const int b = blockIdx.y, tid = threadIdx.x;
     const int cg = C / G;
-    if (tid < G) {
-        gn_group_stats(stats, nsplit_s, G, b, tid, (double)HW * (double)cg, eps, gm[tid], gr[tid]);
-        float a1 = 0.f, a2 = 0.f;
-        for (int c = tid * cg; c < (tid + 1) * cg; ++c) {
-            float t1 = 0.f, t2 = 0.f;
-            for (int sp = 0; sp < nsplit; ++sp) {
-                const float* o = part + ((int64_t)b * nsplit + sp) * 2 * C;
-                t1 += o[c]; t2 += o[C + c];
-            }
-            a1 += gamma[c] * t1; a2 += gamma[c] * t2;
+    // every block needs the per-group sums of the split partials: the channel sums run on all 256 threads (independent loads, splits
+    // in order), then one thread per group adds its channels in order -- the same summation order as one thread per group walking
+    // channels x splits, which at 100+ splits took longer than the streaming pass itself
+    for (int c = tid; c < C; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int sp = 0; sp < nsplit; ++sp) {
+            const float* o = part + ((int64_t)b * nsplit + sp) * 2 * C;
+            t1 += o[c]; t2 += o[C + c];
         }
+        c1[c] = gamma[c] * t1; c2[c] = gamma[c] * t2;
+    }
+    __shared__ double red[256][2];
+    gn_block_stats(stats, nsplit_s, G, b, (double)HW * (double)cg, eps, gm, gr, red);      // (ends with a barrier: c1 / c2 are complete too)
+    if (tid < G) {
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = tid * cg; c < (tid + 1) * cg; ++c) { a1 += c1[c]; a2 += c2[c]; }
         const float n = (float)HW * (float)cg;
         s1[tid] = a1 / n; s2[tid] = a2 / n;
     }
@@ -571,9 +563,9 @@ extern "C" int mumpy_col_sum_fwd(const float* x, float* out, void* workspace, in
     return 0;
 }
 
-static int gn_bwd_splits(int64_t HW, int C) {
-    int64_t s = (HW * C) / 65536;
-    if (s > 64) s = 64;
+static int gn_bwd_splits(int64_t HW, int C) {       // 64 KB of the image per workgroup (as ops.gn_stats): at B = 2 the 256 KB rule
+    int64_t s = (HW * C) / 16384;                   // left 24-128 workgroups, each walking 64 dependent loads (37 us per launch)
+    if (s > 256) s = 256;
     return s < 1 ? 1 : (int)s;
 }
 

@@ -72,6 +72,34 @@ __device__ __forceinline__ float wave_sum(float v, int width) {
     return v;
 }
 
+// GroupNorm: mean / rstd of every group of image b from the split partials {sum, sum of squares} that gn_stats_kernel wrote
+// ([b][split][group][2]).  Every consumer block needs them before it can start; with the partials of up to 256 splits one thread
+// per group walking them in sequence costs more than the streaming pass that follows, so all 256 threads take part: thread
+// (slice k, group g) adds splits k, k + nslice, ... in double, thread g then adds the slices in order (a fixed order: reproducible).
+// Call from ALL threads of a 256-thread block; ends with a barrier.
+__device__ __forceinline__ void gn_block_stats(const float* __restrict__ stats, int nsplit, int G, int b, double n, float eps,
+                                               float* gm, float* gr, double (*red)[2]) {
+    const int tid = threadIdx.x, nslice = 256 / G, g = tid % G, k = tid / G;
+    double s = 0.0, q = 0.0;
+    if (k < nslice)
+        for (int sp = k; sp < nsplit; sp += nslice) {
+            const float* o = stats + (((int64_t)b * nsplit + sp) * G + g) * 2;
+            s += (double)o[0]; q += (double)o[1];
+        }
+    red[tid][0] = s; red[tid][1] = q;
+    __syncthreads();
+    if (tid < G) {
+        double ss = 0.0, qq = 0.0;
+        for (int j = 0; j < nslice; ++j) { ss += red[j * G + tid][0]; qq += red[j * G + tid][1]; }
+        const double m = ss / n;
+        double var = qq / n - m * m;
+        if (var < 0.0) var = 0.0;
+        gm[tid] = (float)m;
+        gr[tid] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+}
+
 // erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, i.e. fp32 round-off level): 1 rcp + 1 exp + 6 fma instead of
 // libm erff's ~40-instruction piecewise path -- the GELU epilogue of the fc1 GEMMs is VALU-bound otherwise.
 __device__ __forceinline__ float erf_fast(float x) {

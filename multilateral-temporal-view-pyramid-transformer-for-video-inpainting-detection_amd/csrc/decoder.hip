@@ -93,21 +93,8 @@ __global__ __launch_bounds__(256) void gn_apply_resample_kernel(ApplyArgs a) {
     const int b = blockIdx.y, tid = threadIdx.x;
     const int C = a.C;
     if (a.partial) {
-        if (tid < a.G) {
-            double s = 0.0, q = 0.0;
-            const float* p = a.partial + ((int64_t)b * a.nsplit * a.G + tid) * 2;
-            for (int k = 0; k < a.nsplit; ++k) {
-                s += (double)p[(int64_t)k * a.G * 2];
-                q += (double)p[(int64_t)k * a.G * 2 + 1];
-            }
-            const double n = (double)a.H * a.W * (C / a.G);
-            const double mean = s / n;
-            double var = q / n - mean * mean;
-            if (var < 0.0) var = 0.0;
-            gm[tid] = (float)mean;
-            gr[tid] = (float)(1.0 / sqrt(var + (double)a.eps));
-        }
-        __syncthreads();
+        __shared__ double red[256][2];
+        gn_block_stats(a.partial, a.nsplit, a.G, b, (double)a.H * a.W * (C / a.G), a.eps, gm, gr, red);
         for (int c = tid; c < C; c += 256) {
             const int g = c / (C / a.G);
             const float s = gr[g] * a.gamma[c];

@@ -500,14 +500,16 @@ struct XPlan { int wt, ks, cps, nchunks, gr, gc; };
 XPlan plan(int R, int C, int KK, int taps = 1) {
     XPlan p;
     const int64_t t128 = (int64_t)((R + 127) / 128) * ((C + 127) / 128) * taps;
-    p.wt = t128 >= 96 ? 64 : 32;                       // wide tiles only when they fill a good part of the chip
+    static const int wide_at = tune_int("MUMPY_XG_WIDE_AT", 96);
+    p.wt = t128 >= wide_at ? 64 : 32;                  // wide tiles only when they fill a good part of the chip
     const int bt = 2 * p.wt;
     p.gr = (R + bt - 1) / bt; p.gc = (C + bt - 1) / bt;
     p.nchunks = (KK + BK - 1) / BK;
     const int64_t tiles = (int64_t)p.gr * p.gc * taps;
-    const int64_t target = p.wt == 64 ? 512 : 768;     // workgroups wanted (2 / 3+ resident per CU)
+    static const int t64 = tune_int("MUMPY_XG_TARGET64", 512), t32 = tune_int("MUMPY_XG_TARGET32", 768), minc = tune_int("MUMPY_XG_MINCHUNKS", 4);
+    const int64_t target = p.wt == 64 ? t64 : t32;     // workgroups wanted (2 / 3+ resident per CU)
     int ks = (int)(target / tiles);
-    if (ks > p.nchunks / 4) ks = p.nchunks / 4;
+    if (ks > p.nchunks / minc) ks = p.nchunks / minc;
     if (ks > 64) ks = 64;
     if (ks < 1) ks = 1;
     p.cps = (p.nchunks + ks - 1) / ks;

@@ -429,7 +429,9 @@ def gn_stats(x, groups):
     """x: logical (B,C,H,W), NHWC memory -> (partial, nsplit)."""
     x = _nhwc(x, "x")
     b, c, h, w = x.shape
-    nsplit = max(1, min(64, (h * w * c) // 65536))
+    # 64 KB of the image per workgroup (16 dependent 16-byte loads per thread): the first rule (256 KB, at most 64 splits) left the
+    # decoder's 28x28 .. 112x112 maps on 24-96 workgroups of 256 CUs, each walking 64 loads in sequence (19 us per launch)
+    nsplit = max(1, min(256, (h * w * c) // 16384))
     partial = torch.empty(b, nsplit, groups, 2, device=x.device, dtype=torch.float32)
     _call("mumpy_gn_stats_nhwc_fwd", _p(x), _p(partial), b, h * w, c, groups, nsplit, _stream(), work=4.0 * x.numel())
     return x, partial, nsplit
