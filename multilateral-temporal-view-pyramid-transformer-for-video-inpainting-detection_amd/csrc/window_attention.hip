@@ -1031,7 +1031,8 @@ extern "C" int mumpy_deform_attention_fwd(const float* q, const float* kv, const
 
 static int64_t wa_bwd_groups(int B, int nW, int nH) {
     const int64_t quads = ((int64_t)B * nW + 3) / 4;
-    int64_t groups = (256 + nH - 1) / nH;                 // ~one 4-wave block per CU (1 wave per SIMD)
+    static const int target = tune_int("MUMPY_WA_BWD_BLOCKS", 256);
+    int64_t groups = (target + nH - 1) / nH;              // ~one 4-wave block per CU (1 wave per SIMD)
     return groups > quads ? quads : groups;
 }
 

@@ -48,9 +48,6 @@ for ev in prof.events():
 dev_names = collections.Counter()
 mem_sites = collections.Counter()
 for ev in prof.events():
-    for k in ev.kernels:
-        if ev.name.startswith("aten::") or ev.cpu_parent is None or not ev.cpu_parent.name.startswith("aten::"):
-            pass
     if ev.kernels and not any(c.kernels for c in ev.cpu_children):          # innermost CPU op owning device work
         for k in ev.kernels:
             dev_names[k.name.split("(")[0][:70]] += 1
