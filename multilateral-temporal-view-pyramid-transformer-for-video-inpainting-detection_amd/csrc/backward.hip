@@ -133,8 +133,8 @@ __global__ __launch_bounds__(1024) void partial_reduce_kernel(const float* __res
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
     float s = 0.f;
-    if (i < width)
-        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * stride + i];
+    if (i < width && grp < nparts)
+        s = ordered_sum(partial[grp * stride + i], partial + (grp + 16) * stride + i, 16 * stride, (int)((nparts - grp + 15) / 16) - 1);
     red[grp][col] = s;
     __syncthreads();
     if (grp == 0 && i < width) {
@@ -153,8 +153,9 @@ __global__ __launch_bounds__(1024) void ln_param_reduce_kernel(const float* __re
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
     float s = 0.f;
-    if (i < 2 * C)
-        for (int64_t p = grp; p < nparts; p += 16) s += partial[p * 2 * C + i];
+    if (i < 2 * C && grp < nparts)
+        s = ordered_sum(partial[(int64_t)grp * 2 * C + i], partial + (int64_t)(grp + 16) * 2 * C + i, (int64_t)32 * C,
+                        (int)((nparts - grp + 15) / 16) - 1);
     red[grp][col] = s;
     __syncthreads();
     if (grp == 0 && i < 2 * C) {

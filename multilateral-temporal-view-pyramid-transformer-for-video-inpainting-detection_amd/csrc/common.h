@@ -72,6 +72,24 @@ __device__ __forceinline__ float wave_sum(float v, int width) {
     return v;
 }
 
+// first + p[stride] + p[2 stride] + ... (n - 1 more terms), added IN THAT ORDER (the reproducibility contract of every slab / partial
+// reduce here), but with the loads of eight terms issued before their adds: written as one load per add with a run-time trip count
+// the loop waits out a memory latency per term, which is most of the duration of the small reduce launches of a training step.
+template <typename T>
+__device__ __forceinline__ T ordered_sum(T first, const T* __restrict__ p, int64_t stride, int n_more) {
+    T s = first;
+    int z = 0;
+    for (; z + 8 <= n_more; z += 8) {
+        T v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(z + u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; z < n_more; ++z) s += p[(int64_t)z * stride];
+    return s;
+}
+
 // GroupNorm: mean / rstd of every group of image b from the split partials {sum, sum of squares} that gn_stats_kernel wrote
 // ([b][split][group][2]).  Every consumer block needs them before it can start; with the partials of up to 256 splits one thread
 // per group walking them in sequence costs more than the streaming pass that follows, so all 256 threads take part: thread

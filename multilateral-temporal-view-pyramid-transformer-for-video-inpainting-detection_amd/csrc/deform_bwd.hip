@@ -95,8 +95,8 @@ __global__ __launch_bounds__(1024) void window_partial_reduce_kernel(const float
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int64_t i = (int64_t)blockIdx.x * 64 + col;
     float s = 0.f;
-    if (i < width)
-        for (int64_t p = grp; p < nparts; p += 16) s += part[p * width + i];
+    if (i < width && grp < nparts)
+        s = ordered_sum(part[grp * width + i], part + (grp + 16) * width + i, 16 * width, (int)((nparts - grp + 15) / 16) - 1);
     red[grp][col] = s;
     __syncthreads();
     if (grp == 0 && i < width) {

@@ -632,8 +632,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
                                                             const float* residual, float* Y, int64_t MN4, int N,
                                                             int ksplit, int act) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MN4; i += (int64_t)gridDim.x * 256) {
-        f32x4 v = reinterpret_cast<const f32x4*>(slab)[i];
-        for (int s = 1; s < ksplit; ++s) v += reinterpret_cast<const f32x4*>(slab)[(int64_t)s * MN4 + i];
+        f32x4 v = ordered_sum(reinterpret_cast<const f32x4*>(slab)[i], reinterpret_cast<const f32x4*>(slab) + MN4 + i, MN4, ksplit - 1);
         const int n = (int)((i * 4) % N);
         if (bias) v += *reinterpret_cast<const f32x4*>(bias + n);
         if (act == MUMPY_ACT_GELU) {

@@ -386,8 +386,7 @@ struct RowSumArgs { const float* slabs; float* out; int R, accum; };     // the 
 __device__ __forceinline__ void reduce_rowsum(const RowSumArgs& rs, int ks) {
     if (!rs.out) return;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < rs.R; i += gridDim.x * 256) {
-        float s = rs.slabs[i];
-        for (int z = 1; z < ks; ++z) s += rs.slabs[(int64_t)z * rs.R + i];
+        const float s = ordered_sum(rs.slabs[i], rs.slabs + rs.R + i, (int64_t)rs.R, ks - 1);
         rs.out[i] = rs.accum ? rs.out[i] + s : s;
     }
 }
@@ -395,8 +394,7 @@ __device__ __forceinline__ void reduce_rowsum(const RowSumArgs& rs, int ks) {
 __global__ __launch_bounds__(256) void xgemm_reduce_kernel(const f32x4* __restrict__ slabs, f32x4* __restrict__ out, int64_t n4,
                                                            int ks, int accum, RowSumArgs rs) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-        f32x4 s = slabs[i];
-        for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * n4 + i];
+        f32x4 s = ordered_sum(slabs[i], slabs + n4 + i, n4, ks - 1);
         if (accum) s += out[i];
         out[i] = s;
     }
@@ -411,16 +409,14 @@ __global__ __launch_bounds__(256) void xgemm_reduce2_kernel(ReduceJob j0, Reduce
     const ReduceJob& j = second ? j1 : j0;
     const unsigned bid = second ? blockIdx.x - j0.blocks : blockIdx.x;
     for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < j.n4; i += (int64_t)j.blocks * 256) {
-        f32x4 s = j.slabs[i];
-        for (int z = 1; z < j.ks; ++z) s += j.slabs[(int64_t)z * j.n4 + i];
+        f32x4 s = ordered_sum(j.slabs[i], j.slabs + j.n4 + i, j.n4, j.ks - 1);
         if (j.accum) s += j.out[i];
         j.out[i] = s;
     }
     if (second) {                                   // the bias-gradient partials ride with the dW job
         if (!rs.out) return;
         for (int i = bid * 256 + threadIdx.x; i < rs.R; i += j1.blocks * 256) {
-            float s = rs.slabs[i];
-            for (int z = 1; z < j1.ks; ++z) s += rs.slabs[(int64_t)z * rs.R + i];
+            const float s = ordered_sum(rs.slabs[i], rs.slabs + rs.R + i, (int64_t)rs.R, j1.ks - 1);
             rs.out[i] = rs.accum ? rs.out[i] + s : s;
         }
     }
@@ -433,8 +429,7 @@ __global__ __launch_bounds__(256) void xgemm_reduce_taps_kernel(const f32x4* __r
     const int c4n = C / 4;
     const int64_t per = (int64_t)taps * R * c4n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per; i += (int64_t)gridDim.x * 256) {
-        f32x4 s = slabs[i];
-        for (int z = 1; z < ks; ++z) s += slabs[(int64_t)z * per + i];
+        f32x4 s = ordered_sum(slabs[i], slabs + per + i, per, ks - 1);
         const int64_t t = i / ((int64_t)R * c4n), rc = i - t * R * c4n;
         const int64_t r = rc / c4n, c4 = rc - r * c4n;
         f32x4* o = reinterpret_cast<f32x4*>(out + (r * taps + t) * C) + c4;
@@ -483,8 +478,8 @@ __global__ __launch_bounds__(1024) void colsum_direct_kernel(const float* __rest
     const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int cc = blockIdx.x * 64 + col;
     float s = 0.f;
-    if (cc < C)
-        for (int64_t r = g; r < R; r += 16) s += x[r * C + cc];
+    if (cc < C && g < R)
+        s = ordered_sum(x[(int64_t)g * C + cc], x + (int64_t)(g + 16) * C + cc, (int64_t)16 * C, (int)((R - g + 15) / 16) - 1);
     red[g][col] = s;
     __syncthreads();
     if (g == 0 && cc < C) {

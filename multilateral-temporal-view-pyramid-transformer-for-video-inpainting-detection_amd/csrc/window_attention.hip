@@ -889,11 +889,11 @@ __global__ __launch_bounds__(256) void win_attn_dbias_reduce_kernel(const float*
     const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
     const int idx = blockIdx.x * 64 + col;                                // element of the 4096-float partial
     const int nparts = ((nblocks - head + nH - 1) / nH) * 4;             // this head's blocks x 4 waves
+    // lane group grp takes wave grp of every block of this head, blocks in order: terms nH * 4 * 4096 floats apart
     float s = 0.f;
-    for (int p = grp; p < nparts; p += 4) {
-        const int blk = head + (p >> 2) * nH, w = p & 3;
-        s += part[((int64_t)blk * 4 + w) * 4096 + idx];
-    }
+    if (grp < nparts)
+        s = ordered_sum(part[((int64_t)head * 4 + grp) * 4096 + idx], part + ((int64_t)(head + nH) * 4 + grp) * 4096 + idx,
+                        (int64_t)nH * 4 * 4096, nparts / 4 - 1);
     red[grp][col] = s;
     __syncthreads();
     if (grp) return;
