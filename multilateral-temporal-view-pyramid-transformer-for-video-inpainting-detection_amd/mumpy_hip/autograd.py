@@ -100,7 +100,7 @@ class LinearFn(torch.autograd.Function):
 
 
 LEGACY_LINEAR_BWD = os.environ.get("MUMPY_LEGACY_LINEAR_BWD", "0") != "0"   # the first version's route (transposes + forward GEMM), for A/B runs
-BIG_DGRAD_ROWS = 4096
+BIG_DGRAD_ROWS = int(os.environ.get("MUMPY_BIG_DGRAD_ROWS", "16384"))     # tools/big_dgrad_sweep.sh: at B = 2 the step is flat in this (4096 .. never)
 
 
 def _residual_linear(x_res, drop_path, inp, lin_w, lin_b):
