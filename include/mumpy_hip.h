@@ -304,6 +304,14 @@ int mumpy_gn_apply_resample_nhwc_fwd(const float* x, const float* partial, int n
 int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const float* bias, float* logits, uint8_t* mask, int B,
                          int H, int W, int C, float thr, void* stream);
 
+/* Backward of mumpy_final_conv_fwd for C = 32 (the three-view Decoder's final_out under loss.backward(), decoder.py:95,225):
+ * x (B,H,W,32) NHWC, w_krsc (1,3,3,32), dy (B,H,W) -> dx (B,H,W,32), dw (3,3,32) and db (1), all written (not accumulated).
+ * One streaming pass + a fixed-tree reduce of one partial row per workgroup: deterministic.
+ * workspace: mumpy_final_conv_bwd_workspace_bytes(B,H,W) bytes. */
+int64_t mumpy_final_conv_bwd_workspace_bytes(int B, int H, int W);
+int mumpy_final_conv_bwd(const float* x, const float* w_krsc, const float* dy, float* dx, float* dw, float* db, void* workspace,
+                         int64_t workspace_bytes, int B, int H, int W, int C, void* stream);
+
 /* ---- eval tail: sigmoid -> >0.5 -> uint8 mask  — test.py:100-108 ----------------------- */
 int mumpy_sigmoid_threshold_fwd(const float* logits, uint8_t* mask, int64_t n, float thr, void* stream);
 

@@ -202,6 +202,92 @@ __global__ __launch_bounds__(256) void final_conv_kernel(const float* __restrict
     }
 }
 
+// Backward of that convolution (config 5's training step; decoder.py:95,225 under loss.backward()) in one streaming pass:
+//   dx[p][c]        = sum_taps w[tap][c] dy[p - tap]          (the pixel that read p through the tap)
+//   dw[tap][c]      = sum_p dy[p] x[p + tap][c],   db = sum_p dy[p]
+// Same thread layout as the forward (8 lanes x 4 channels per pixel, 32 pixels per pass, contiguous runs per workgroup, XCD-major).
+// A thread keeps the nine 4-channel weight-gradient sums of its pixels in registers; a workgroup combines its 32 pixel lanes in a
+// fixed order (three shuffles, then the four waves through LDS) and writes ONE partial row [9][32] + [1]; partial_reduce sums the
+// rows in a fixed tree.  The first version embedded dy in a 32-channel image for the generic convolution (dx) and ran nine
+// M = 1, K = B H W GEMMs on shifted, transposed copies of x (130 us each) for dw: 1.6 ms of a 42 ms step.
+constexpr int FCB_ROW = 9 * 32 + 4;                   // partial row: dw (288) | db | 3 pad
+__global__ __launch_bounds__(256) void final_conv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ dy, float* __restrict__ dx,
+                                                             float* __restrict__ part, int H, int W, int64_t npix) {
+    __shared__ f32x4 red[4][9][8];
+    __shared__ float redb[4];
+    const int sub = threadIdx.x & 7, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 wr[9], gw[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { wr[t] = *reinterpret_cast<const f32x4*>(w + t * 32 + 4 * sub); gw[t] = f32x4{0, 0, 0, 0}; }
+    float gb = 0.f;
+    const unsigned G = gridDim.x, xcd = blockIdx.x & 7, q8 = G >> 3, r8 = G & 7;
+    const int64_t vb = (xcd < r8 ? (int64_t)xcd * (q8 + 1) : (int64_t)r8 * (q8 + 1) + (int64_t)(xcd - r8) * q8) + (blockIdx.x >> 3);
+    const int64_t per = (npix + G - 1) / G;
+    const int64_t pend = (vb + 1) * per < npix ? (vb + 1) * per : npix;
+    for (int64_t pix = vb * per + (threadIdx.x >> 3); pix < pend; pix += 32) {
+        const int xx = (int)(pix % W);
+        const int yy = (int)((pix / W) % H);
+        const float d0 = dy[pix];
+        f32x4 acc = {0, 0, 0, 0};
+#pragma unroll
+        for (int ky = -1; ky <= 1; ++ky)
+#pragma unroll
+            for (int kx = -1; kx <= 1; ++kx) {
+                const int t = (ky + 1) * 3 + kx + 1;
+                // forward: out[y][x] += w[t] . in[y + ky][x + kx]  =>  in[yy][xx] was read by out[yy - ky][xx - kx] through tap t
+                if ((unsigned)(yy - ky) < (unsigned)H && (unsigned)(xx - kx) < (unsigned)W) acc += wr[t] * dy[pix - ky * W - kx];
+                if ((unsigned)(yy + ky) < (unsigned)H && (unsigned)(xx + kx) < (unsigned)W)
+                    gw[t] += *reinterpret_cast<const f32x4*>(x + (pix + ky * W + kx) * 32 + 4 * sub) * d0;
+            }
+        *reinterpret_cast<f32x4*>(dx + pix * 32 + 4 * sub) = acc;
+        if (sub == 0) gb += d0;
+    }
+    // pixel lanes of a wave: lanes with equal `sub` are 8 apart -> xor 8, 16, 32 (every lane takes part: zeros where no pixel)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = gw[t][e];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+            gw[t][e] = v;
+        }
+    gb += __shfl_xor(gb, 8); gb += __shfl_xor(gb, 16); gb += __shfl_xor(gb, 32);
+    if (lane < 8) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) red[wave][t][sub] = gw[t];
+        if (lane == 0) redb[wave] = gb;
+    }
+    __syncthreads();
+    float* row = part + (int64_t)blockIdx.x * FCB_ROW;
+    if (threadIdx.x < 72) {
+        const int t = threadIdx.x >> 3, q = threadIdx.x & 7;
+        const f32x4 v = (red[0][t][q] + red[1][t][q]) + (red[2][t][q] + red[3][t][q]);
+        *reinterpret_cast<f32x4*>(row + t * 32 + 4 * q) = v;
+    }
+    if (threadIdx.x == 72) *reinterpret_cast<f32x4*>(row + 288) = f32x4{(redb[0] + redb[1]) + (redb[2] + redb[3]), 0.f, 0.f, 0.f};
+}
+
+// fixed-tree column sums of the partial rows (64 columns per block, 16 row lanes, combined in order through LDS)
+__global__ __launch_bounds__(1024) void fcb_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ db,
+                                                          int64_t nparts) {
+    __shared__ float red[16][64];
+    const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
+    float s = 0.f;
+    if (i < 289 && grp < nparts)
+        s = ordered_sum(part[(int64_t)grp * FCB_ROW + i], part + (int64_t)(grp + 16) * FCB_ROW + i, (int64_t)16 * FCB_ROW,
+                        (int)((nparts - grp + 15) / 16) - 1);
+    red[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < 289) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) t += red[g][col];
+        if (i < 288) dw[i] = t; else db[0] = t;
+    }
+}
+
 // same conv for C = 32*k input channels (BaselineDecoder.final_out is Conv2d(256 -> 1), decoder:275): the 8 lanes of a
 // pixel walk the channel blocks, weights come from L1 instead of registers.
 __global__ __launch_bounds__(256) void final_conv_wide_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -427,6 +513,33 @@ extern "C" int mumpy_final_conv_fwd(const float* x, const float* w_krsc, const f
         hipLaunchKernelGGL(final_conv_wide_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, bias,
                            logits, mask, H, W, C, npix, thr);
     MUMPY_CHECK_LAUNCH("final_conv");
+    return 0;
+}
+
+static int64_t fcb_blocks(int64_t npix) {            // contiguous runs of >= 128 pixels, at most 2048 workgroups
+    int64_t g = (npix + 127) / 128;
+    if (g > 2048) g = 2048;
+    return g < 1 ? 1 : g;
+}
+
+extern "C" int64_t mumpy_final_conv_bwd_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return fcb_blocks((int64_t)B * H * W) * FCB_ROW * (int64_t)sizeof(float);
+}
+
+extern "C" int mumpy_final_conv_bwd(const float* x, const float* w_krsc, const float* dy, float* dx, float* dw, float* db,
+                                    void* workspace, int64_t workspace_bytes, int B, int H, int W, int C, void* stream) {
+    MUMPY_REQUIRE(x && w_krsc && dy && dx && dw && db && workspace, MUMPY_ENULL, "final_conv_bwd: null pointer");
+    MUMPY_REQUIRE(aligned16(x) && aligned16(w_krsc) && aligned16(dx) && aligned16(workspace), MUMPY_EALIGN,
+                  "final_conv_bwd: x, w, dx and the workspace must be 16-byte aligned");
+    MUMPY_REQUIRE(B > 0 && H > 0 && W > 0 && C == 32, MUMPY_EINVAL, "final_conv_bwd: built for C = 32 input channels (got %d)", C);
+    MUMPY_REQUIRE(workspace_bytes >= mumpy_final_conv_bwd_workspace_bytes(B, H, W), MUMPY_EINVAL, "final_conv_bwd: workspace too small");
+    const int64_t npix = (int64_t)B * H * W, grid = fcb_blocks(npix);
+    float* part = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(final_conv_bwd_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), x, w_krsc, dy, dx, part, H, W, npix);
+    MUMPY_CHECK_LAUNCH("final_conv_bwd");
+    hipLaunchKernelGGL(fcb_reduce_kernel, dim3(5), dim3(1024), 0, as_stream(stream), part, dw, db, grid);
+    MUMPY_CHECK_LAUNCH("final_conv_bwd(reduce)");
     return 0;
 }
 

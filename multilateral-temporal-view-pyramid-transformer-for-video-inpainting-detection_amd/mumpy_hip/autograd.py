@@ -394,8 +394,9 @@ class UpsampleFn(torch.autograd.Function):
 
 
 class FinalConvFn(torch.autograd.Function):
-    """Conv2d(C -> 1, 3x3) (mumpy_final_conv_fwd).  Backward through the generic conv path with the single output channel
-    embedded in a 32-channel gradient image (the implicit-GEMM kernel wants channel counts in multiples of 32)."""
+    """Conv2d(C -> 1, 3x3) (mumpy_final_conv_fwd).  Backward: mumpy_final_conv_bwd for C = 32 (the three-view Decoder); other widths
+    go through the generic conv path with the single output channel embedded in a 32-channel gradient image (the implicit-GEMM
+    kernel wants channel counts in multiples of 32) and one M = 1 GEMM per tap -- fine for a test, 1.6 ms per step at 224 x 224."""
 
     @staticmethod
     def forward(ctx, x, w_krsc, bias):
@@ -406,6 +407,8 @@ class FinalConvFn(torch.autograd.Function):
     def backward(ctx, dy):                                         # dy (B,1,H,W)
         x, w = ctx.saved_tensors                                   # w (1,3,3,C)
         b, c, h, wd = x.shape
+        if c == 32 and not LEGACY_LINEAR_BWD:
+            return ops.final_conv_bwd(x, w, dy.contiguous())
         dyp = torch.zeros(b, h, wd, 32, device=dy.device, dtype=torch.float32)
         dyp[..., 0] = dy[:, 0]
         wt = torch.zeros(c, 3, 3, 32, device=dy.device, dtype=torch.float32)

@@ -68,6 +68,8 @@ SIGNATURES = {
     "mumpy_transpose_fwd": [c_f, c_f, c_l, c_l, c_f],
     "mumpy_col_sum_workspace_bytes": [c_l, c_i],
     "mumpy_col_sum_fwd": [c_f, c_f, c_f, c_l, c_l, c_i, c_f],
+    "mumpy_final_conv_bwd_workspace_bytes": [c_i, c_i, c_i],
+    "mumpy_final_conv_bwd": [c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f],
     "mumpy_patch_gather_fwd": [c_f, c_f, c_l, c_i, c_i, c_i, c_i, c_f],
     "mumpy_conv_weight_dgrad_fwd": [c_f, c_f, c_i, c_i, c_i, c_i, c_f],
     "mumpy_conv2d_wgrad_workspace_bytes": [c_i, c_i, c_i, c_i, c_i, c_i, c_i],

@@ -889,6 +889,24 @@ def linear_bwd(x2d, weight, dy2d, need_dx=True, dw_out=None, db_out=None, need_d
     return dx, (None if dw_out is not None else dw), (None if db_out is not None else db)
 
 
+def final_conv_bwd(x, w_krsc, dy):
+    """Backward of final_conv for C = 32: x logical (B,32,H,W) NHWC, w_krsc (1,3,3,32), dy (B,1,H,W) ->
+    (dx like x, dw (1,3,3,32), db (1,)).  One streaming pass + a small fixed-tree reduce."""
+    x = _nhwc(x, "x")
+    b, c, h, w = x.shape
+    dy = _chk(dy.reshape(b, h, w), "dy")
+    if c != 32 or tuple(w_krsc.shape) != (1, 3, 3, 32):
+        raise RuntimeError(f"final_conv_bwd is built for Conv2d(32, 1, 3, padding=1); got C={c}, weight {tuple(w_krsc.shape)}")
+    dx = empty_nhwc(b, c, h, w, x.device)
+    dw = torch.empty(1, 3, 3, 32, device=x.device, dtype=torch.float32)
+    db = torch.empty(1, device=x.device, dtype=torch.float32)
+    wsb = int(_lib().mumpy_final_conv_bwd_workspace_bytes(b, h, w))
+    ws = _ws(wsb, x.device)
+    _call("mumpy_final_conv_bwd", _p(x), _p(_chk(w_krsc, "weight")), _p(dy), _p(dx), _p(dw), _p(db), _p(ws), wsb, b, h, w, c, _stream(),
+          work=4.0 * (2 * x.numel() + dy.numel()))
+    return dx, dw, db
+
+
 def patch_gather(x, b, h, w, c, inverse=False):
     """PatchMerging's 2x2 gather (swin:357-361): x (b,h,w,c) -> (b, h/2 * w/2, 4c); inverse=True maps a merged-layout tensor back to
     (b, h*w, c) (the gather's backward) -- one permutation launch either way."""

@@ -383,6 +383,24 @@ def test_hip_conv_weight_dgrad_and_channels_last_slots():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("b,h,w", [(2, 13, 11), (1, 1, 1), (2, 224, 224), (3, 40, 7)])
+def test_hip_final_conv_backward(b, h, w):
+    """FinalConvFn (Conv2d(32 -> 1, 3x3, padding 1)) backward -- the one-pass kernel mumpy_final_conv_bwd -- against torch autograd:
+    dx, dw, db; ragged sizes exercise the image borders and the partial-row reduce."""
+    from mumpy_hip.autograd import FinalConvFn
+    x, wt, bs = seeded_randn(50, b, 32, h, w), seeded_randn(51, 1, 32, 3, 3) / 17.0, seeded_randn(52, 1)
+    dy = seeded_randn(53, b, 1, h, w)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, wt, bs)]
+    F.conv2d(xr, wr, br, padding=1).backward(dy)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wg, bg = wt.cuda().requires_grad_(True), bs.cuda().requires_grad_(True)
+    y = FinalConvFn.apply(xg, wg.permute(0, 2, 3, 1).contiguous(), bg)
+    assert rel_err(y.detach().cpu(), F.conv2d(x, wt, bs, padding=1)) < 1e-5
+    y.backward(dy.cuda())
+    assert rel_err(xg.grad.cpu(), xr.grad) < 2e-5 and rel_err(wg.grad.cpu(), wr.grad) < 2e-5 and rel_err(bg.grad.cpu(), br.grad) < 2e-5
+
+
+@pytest.mark.gpu
 def test_hip_baseline_decoder_backward_vs_oracle():
     """config 1's decoder: logits and every parameter gradient against autograd on the oracle (B=2)."""
     from models.decoder.decoder import BaselineDecoder
