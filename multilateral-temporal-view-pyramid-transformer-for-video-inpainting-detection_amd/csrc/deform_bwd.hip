@@ -140,10 +140,26 @@ __global__ __launch_bounds__(256) void deform_sample_bwd_kernel(const float* __r
     int* cnt = reinterpret_cast<int*>(sc + WT * 4);
     int* lp = cnt + WT;                                           // [pixel][SB_LIST] point index
     float* lw = reinterpret_cast<float*>(lp + WT * SB_LIST);      // [pixel][SB_LIST] weight
-    for (int i = threadIdx.x; i < WT * Cg; i += 256) {
-        const int c = i % Cg, p = i / Cg;
-        sx[i] = x2[((int64_t)b2 * WT + p) * C + g * Cg + c];
-        sd[i] = ds[((int64_t)b2 * WT + p) * C + g * Cg + c];
+    // 16-byte loads, four per array in flight before the LDS writes (Cg is a multiple of 32): at the late stages the launch is 6-30
+    // workgroups, and one 4-byte load per loop step made this staging loop 49 memory latencies long -- most of the kernel
+    const int cg4 = Cg >> 2, n4 = WT * cg4;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 1024) {
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n4) {
+                const int c4 = i % cg4, p = i / cg4;
+                const int64_t o = ((int64_t)b2 * WT + p) * C + g * Cg + 4 * c4;
+                va[u] = *reinterpret_cast<const f32x4*>(x2 + o);
+                vb[u] = *reinterpret_cast<const f32x4*>(ds + o);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 256 * u;
+            if (i < n4) { reinterpret_cast<f32x4*>(sx)[i] = va[u]; reinterpret_cast<f32x4*>(sd)[i] = vb[u]; }
+        }
     }
     const float* pq = pos + ((int64_t)(b2 % nq) * 3 + g) * WT * 2;
     if (threadIdx.x < WT) {
@@ -238,7 +254,8 @@ extern "C" int mumpy_dwconv5_window_bwd(const float* x, const float* w, const fl
 extern "C" int mumpy_deform_sample_bwd(const float* x2, const float* pos, const float* dsampled, float* dx2, float* dpos_part,
                                        int64_t B2, int C, int nq, void* stream) {
     MUMPY_REQUIRE(x2 && pos && dsampled && dx2 && dpos_part, MUMPY_ENULL, "deform_sample_bwd: null pointer");
-    MUMPY_REQUIRE(B2 > 0 && B2 < (1ll << 31) && C > 0 && C % 3 == 0 && C <= 768 && nq > 0, MUMPY_EINVAL, "deform_sample_bwd: bad shape");
+    MUMPY_REQUIRE(B2 > 0 && B2 < (1ll << 31) && C > 0 && C % 12 == 0 && C <= 768 && nq > 0, MUMPY_EINVAL, "deform_sample_bwd: bad shape (C %% 12)");
+    MUMPY_REQUIRE(aligned16(x2) && aligned16(dsampled), MUMPY_EALIGN, "deform_sample_bwd: x2 and dsampled must be 16-byte aligned");
     const size_t lds = (2 * WT * (C / 3) + WT * 2 + WT * 4 + WT + 2 * WT * WT) * sizeof(float);      // slices, pos, corners, counts, lists
     MUMPY_REQUIRE(lds <= 160 * 1024, MUMPY_ERANGE, "deform_sample_bwd: window does not fit LDS");
     if (lds > 64 * 1024) {
