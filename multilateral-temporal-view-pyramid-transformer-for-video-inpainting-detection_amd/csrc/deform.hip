@@ -32,13 +32,32 @@ __global__ __launch_bounds__(256) void deform_offsets_kernel(const float* __rest
     const int64_t L = (int64_t)H * W;
     const float* qb = q + (int64_t)b * L * C + g * Cg;
     const int cg4 = Cg >> 2;
-    for (int idx = tid; idx < WT * cg4; idx += 256) {
-        const int p = idx / cg4, c4 = idx - p * cg4;
-        const int tok = window_token(wy, wx, p, H, W, 0);
-        *reinterpret_cast<f32x4*>(tile + p * Cg + 4 * c4) = *reinterpret_cast<const f32x4*>(qb + (int64_t)tok * C + 4 * c4);
+    // staging: every 16-byte load of a thread is issued before its first LDS write (at the late stages a launch is 24-96 workgroups
+    // and its duration is one workgroup's dependent chain: a load per loop step would add a memory latency per step)
+    {
+        constexpr int NT = WT * (Cg / 4), PT = (NT + 255) / 256;
+        f32x4 v[PT];
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NT) {
+                const int p = idx / cg4, c4 = idx - p * cg4;
+                v[u] = *reinterpret_cast<const f32x4*>(qb + (int64_t)window_token(wy, wx, p, H, W, 0) * C + 4 * c4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PT; ++u) {
+            const int idx = tid + 256 * u;
+            if (idx < NT) { const int p = idx / cg4, c4 = idx - p * cg4; *reinterpret_cast<f32x4*>(tile + p * Cg + 4 * c4) = v[u]; }
+        }
+        // the group's 25 taps per channel (shared by the groups) and, below, the per-channel parameters of the LayerNorm / 1x1 stage
+        constexpr int NW = 25 * Cg / 4, PW = (NW + 255) / 256;
+        f32x4 t[PW];
+#pragma unroll
+        for (int u = 0; u < PW; ++u) { const int idx = tid + 256 * u; if (idx < NW) t[u] = reinterpret_cast<const f32x4*>(dw_w)[idx]; }
+#pragma unroll
+        for (int u = 0; u < PW; ++u) { const int idx = tid + 256 * u; if (idx < NW) reinterpret_cast<f32x4*>(wsm)[idx] = t[u]; }
     }
-    // the group's 25 taps per channel and the per-channel parameters of the LayerNorm / 1x1 stage: coalesced into LDS
-    for (int idx = tid; idx < 25 * Cg; idx += 256) wsm[idx] = dw_w[idx];
     for (int idx = tid; idx < Cg; idx += 256) {
         par[idx] = ln_g[idx];
         par[Cg + idx] = ln_b[idx];
@@ -249,7 +268,7 @@ extern "C" int mumpy_deform_offsets_fwd(const float* q, const float* dw_w, const
                                         const float* ln_b, const float* pw_w, float* pos, int B, int H, int W, int C,
                                         void* stream) {
     MUMPY_REQUIRE(q && dw_w && dw_b && ln_g && ln_b && pw_w && pos, MUMPY_ENULL, "deform_offsets: null pointer");
-    MUMPY_REQUIRE(aligned16(q), MUMPY_EALIGN, "deform_offsets: q must be 16-byte aligned");
+    MUMPY_REQUIRE(aligned16(q) && aligned16(dw_w), MUMPY_EALIGN, "deform_offsets: q and the depthwise weights must be 16-byte aligned");
     MUMPY_REQUIRE(B > 0 && H % WS == 0 && W % WS == 0 && H > 0 && W > 0, MUMPY_EINVAL, "deform_offsets: bad grid (%d,%d)", H, W);
     const int Cg = C / 3;
     MUMPY_REQUIRE(C % 3 == 0 && (Cg == 32 || Cg == 64 || Cg == 128 || Cg == 256), MUMPY_EINVAL,
