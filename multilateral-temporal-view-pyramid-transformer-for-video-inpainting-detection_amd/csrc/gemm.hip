@@ -701,10 +701,12 @@ Plan make_plan(int64_t M, int N, int K, bool allow_split, bool x3 = false) {
     // co-resident blocks, lowest LDS-read ratio) measured 4-9 % faster than the 8-wave pipelined one
     if (tile == 0 && b128 > NUM_CU && K >= 512) tile = 3;
     int ks = 1;
-    if (tile == 2 && allow_split && b64 < 2 * NUM_CU && K >= 768) {
+    static const int min_slice = tune_int("MUMPY_GEMM_MINSLICE", 384), max_ks = tune_int("MUMPY_GEMM_MAXKS", 16),
+                     min_k = tune_int("MUMPY_GEMM_SPLIT_MINK", 768);
+    if (tile == 2 && allow_split && b64 < 2 * NUM_CU && K >= min_k) {
         ks = (int)((3 * NUM_CU + b64 - 1) / b64);
-        if (ks > K / 384) ks = K / 384;
-        if (ks > 16) ks = 16;
+        if (ks > K / min_slice) ks = K / min_slice;
+        if (ks > max_ks) ks = max_ks;
         while (ks > 1 && (K % (32 * ks)) != 0) --ks;
         if (ks < 1) ks = 1;
     }
